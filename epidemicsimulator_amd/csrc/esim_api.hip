@@ -1,0 +1,572 @@
+// esim_api.hip -- host side of libesim: the C ABI of include/esim.h over the kernels of
+// esim_kernels.hip.  No CPU compute path exists here: without a HIP device every entry
+// point that would compute fails with ESIM_ENODEVICE.
+#include "esim_kernels.hip"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct esim_ctx_impl {
+    esim_params P;
+    Dev d;
+    bool uploaded = false;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // host copies needed for reset
+    std::vector<uint16_t> init_state;
+    size_t cnt_bytes = 0;
+    size_t xa_n = 0, xb_n = 0;
+    uint32_t host_t = 1;          // next time step to enqueue
+    // device allocations
+    std::vector<void *> allocs;
+    // timing
+    bool phase_timing = false, kernel_timing = false;
+    uint32_t kernel_timing_stride = 16;
+    hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    double phase_s[3] = { 0, 0, 0 };
+    std::vector<hipEvent_t> kev;       // quadruples: tick start/stop, expose start/stop
+    size_t kev_used = 0;
+    uint32_t grid_citizens = 1, grid_bus_small = 1, grid_bus_big = 1;
+};
+
+#define CTX(c) (reinterpret_cast<esim_ctx_impl *>(c))
+
+int fail(esim_ctx_impl *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(c, ESIM_ENODEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+template <class T> int dev_alloc(esim_ctx_impl *c, T **p, size_t n)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, sizeof(T) * (n ? n : 1));
+    if (e != hipSuccess) return fail(c, ESIM_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    c->allocs.push_back(q);
+    *p = (T *)q;
+    return ESIM_OK;
+}
+
+template <class T> int dev_upload(esim_ctx_impl *c, const T **p, const T *host, size_t n)
+{
+    T *q = nullptr;
+    int rc = dev_alloc(c, &q, n);
+    if (rc) return rc;
+    if (n) HIP_TRY(c, hipMemcpy(q, host, sizeof(T) * n, hipMemcpyHostToDevice));
+    *p = q;
+    return ESIM_OK;
+}
+
+void free_device(esim_ctx_impl *c)
+{
+    for (void *p : c->allocs) (void)hipFree(p);
+    c->allocs.clear();
+    c->uploaded = false;
+}
+
+uint32_t grid_for(size_t items, uint32_t per_block, uint32_t cap)
+{
+    size_t g = (items + per_block - 1) / per_block;
+    return (uint32_t)std::max<size_t>(1, std::min<size_t>(g, cap));
+}
+
+}  // namespace
+
+extern "C" void esim_default_params(esim_params *p)
+{
+    if (!p) return;
+    p->exposure_chance = 0.00055; p->mask_effectiveness = 0.70;            // disease.rs:120,127
+    p->lockdown_threshold = 0.0034; p->vaccination_threshold = 0.005;      // interventions.rs:74-75
+    p->mask_pt_threshold = 0.001; p->mask_everywhere_threshold = 0.0022;   // interventions.rs:55-56
+    p->exposed_time = 4 * 24; p->infected_time = 14 * 24;                  // disease.rs:122-123
+    p->vaccination_rate = 85 * 18;                                         // disease.rs:125
+    p->bus_capacity = 20;                                                  // config.rs:37
+    p->start_hour = 9; p->end_hour = 17;                                   // citizen.rs:154-155
+    p->seed = 0x5EED2011ull;
+    p->device = 0;
+    p->max_steps = 5000;                                                   // disease.rs:124
+}
+
+// ceil(q * 2^53): `uniform < q` (citizen.rs:242) for uniform = u53 * 2^-53 is exactly
+// `u53 < ceil(q * 2^53)`, because scaling a double by 2^53 is exact.
+extern "C" int esim_threshold_lut(const esim_params *p, uint64_t out[512])
+{
+    if (!p || !out) return ESIM_EINVAL;
+    for (int row = 0; row < 2; ++row) {
+        // DiseaseModel::get_exposure_chance, disease.rs:131-154 (is_vaccinated = false: only
+        // Susceptible citizens are ever tested, simulator.rs:337,436)
+        double chance = p->exposure_chance - (row ? p->exposure_chance * p->mask_effectiveness : 0.0) - 0.0;
+        if (std::signbit(chance)) chance = 0.0;
+        for (int n = 0; n < 256; ++n) {
+            const double q = 1.0 - std::pow(1.0 - chance, (double)n);      // binomial, citizen.rs:47-49
+            const double scaled = std::ceil(std::ldexp(q, 53));
+            out[row * 256 + n] = scaled <= 0.0 ? 0ull : (uint64_t)scaled;
+        }
+    }
+    return ESIM_OK;
+}
+
+extern "C" int esim_create(const esim_params *p, esim_ctx **out)
+{
+    if (!p || !out) return fail(nullptr, ESIM_EINVAL, "esim_create: null argument");
+    if (p->exposed_time + p->infected_time + 2u > TE_BIAS)
+        return fail(nullptr, ESIM_ERANGE, "esim_create: exposed_time + infected_time + 2 exceeds the state encoding (512)");
+    if (p->vaccination_rate > VACC_MAX_RATE)
+        return fail(nullptr, ESIM_ERANGE, "esim_create: vaccination_rate above 8192 is not supported");
+    if (p->bus_capacity == 0 || p->start_hour == 0 || p->end_hour == 0 || p->start_hour > 24 || p->end_hour > 24)
+        return fail(nullptr, ESIM_EINVAL, "esim_create: bad bus_capacity / working hours");
+    if (p->max_steps == 0 || p->max_steps > ESIM_MAX_STEP)
+        return fail(nullptr, ESIM_ERANGE, "esim_create: max_steps must be in 1..7600");
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return fail(nullptr, ESIM_ENODEVICE, std::string("esim_create: no HIP device (") + hipGetErrorString(e) + ")");
+    if (p->device < 0 || p->device >= n_dev) return fail(nullptr, ESIM_EINVAL, "esim_create: device ordinal out of range");
+    e = hipSetDevice(p->device);
+    if (e != hipSuccess) return fail(nullptr, ESIM_ENODEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    esim_ctx_impl *c = new esim_ctx_impl();
+    c->P = *p;
+    std::memset(&c->d, 0, sizeof c->d);
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(nullptr, ESIM_ENODEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    for (auto &ev : c->ev) (void)hipEventCreate(&ev);
+    *out = reinterpret_cast<esim_ctx *>(c);
+    return ESIM_OK;
+}
+
+extern "C" void esim_destroy(esim_ctx *ctx)
+{
+    if (!ctx) return;
+    esim_ctx_impl *c = CTX(ctx);
+    (void)hipSetDevice(c->P.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_device(c);
+    for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->kev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char *esim_last_error(const esim_ctx *ctx)
+{
+    if (!ctx) return g_create_error.c_str();
+    return reinterpret_cast<const esim_ctx_impl *>(ctx)->err.c_str();
+}
+
+extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !pop) return fail(c, ESIM_EINVAL, "esim_upload_population: null argument");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    const uint32_t N = pop->n_citizens, B = pop->n_buildings, R = pop->n_rooms;
+    if (!pop->home_building || !pop->work_building || !pop->room || !pop->flags || !pop->building_area || !pop->building_type)
+        return fail(c, ESIM_EINVAL, "esim_upload_population: a required array is NULL");
+    if (R && !pop->room_building) return fail(c, ESIM_EINVAL, "esim_upload_population: room_building is NULL");
+    if (pop->n_seeds && !pop->seeds) return fail(c, ESIM_EINVAL, "esim_upload_population: seeds is NULL");
+    const uint32_t n_global = pop->n_citizens_global ? pop->n_citizens_global : N;
+    if ((uint64_t)pop->citizen_id_base + N > n_global) return fail(c, ESIM_EINVAL, "esim_upload_population: shard range exceeds n_citizens_global");
+    const bool sharded = n_global != N || pop->n_shared_buildings || pop->n_shared_rooms;
+    // ---- validate the population contract and derive the static flags
+    std::vector<uint8_t> fl(N);
+    for (uint32_t b = 0; b < B; ++b) {
+        if (pop->building_area[b] >= pop->n_areas) return fail(c, ESIM_EINVAL, "esim_upload_population: building_area out of range");
+        if (pop->building_type[b] > ESIM_SCHOOL) return fail(c, ESIM_EINVAL, "esim_upload_population: unknown building_type");
+    }
+    for (uint32_t r = 0; r < R; ++r)
+        if (pop->room_building[r] >= B || pop->building_type[pop->room_building[r]] != ESIM_SCHOOL)
+            return fail(c, ESIM_EINVAL, "esim_upload_population: room_building must name a School");
+    std::vector<uint32_t> room_fixed(N, 0);
+    for (uint32_t i = 0; i < N; ++i) {
+        const uint32_t hb = pop->home_building[i], wb = pop->work_building[i];
+        if (hb >= B || wb >= B) return fail(c, ESIM_EINVAL, "esim_upload_population: building index out of range");
+        if (pop->building_type[hb] == ESIM_SCHOOL) return fail(c, ESIM_EINVAL, "esim_upload_population: a School cannot be a home");
+        uint8_t f = pop->flags[i] & (FL_USES_PT | FL_MASK_COMPLIANT);
+        if (pop->building_area[hb] == pop->building_area[wb]) f |= FL_SAME_AREA;
+        if (hb != wb) {
+            f |= FL_HAS_WORK;
+            if (pop->building_type[wb] == ESIM_SCHOOL) {
+                f |= FL_WORK_SCHOOL;
+                if (pop->room[i] >= R || pop->room_building[pop->room[i]] != wb)
+                    return fail(c, ESIM_EINVAL, "esim_upload_population: school member without a room of that school");
+                room_fixed[i] = pop->room[i];
+            }
+        }
+        fl[i] = f;
+    }
+    for (uint32_t i = 0; i < pop->n_seeds; ++i)
+        if (pop->seeds[i] >= N) return fail(c, ESIM_EINVAL, "esim_upload_population: seed index out of range");
+    for (uint32_t i = 0; i < pop->n_shared_buildings; ++i)
+        if (pop->shared_building_local[i] >= (int32_t)B) return fail(c, ESIM_EINVAL, "esim_upload_population: shared building out of range");
+    for (uint32_t i = 0; i < pop->n_shared_rooms; ++i)
+        if (pop->shared_room_local[i] >= (int32_t)R) return fail(c, ESIM_EINVAL, "esim_upload_population: shared room out of range");
+
+    // ---- public transport routes: riders sharing (home area, work area), simulator.rs:181-186.
+    // Both travel directions group the same citizens, so one static list serves every bus step.
+    std::vector<std::pair<uint64_t, uint32_t>> pairs;
+    for (uint32_t i = 0; i < N; ++i)
+        if (fl[i] & FL_USES_PT)
+            pairs.emplace_back(((uint64_t)pop->building_area[pop->home_building[i]] << 32) | pop->building_area[pop->work_building[i]], i);
+    std::sort(pairs.begin(), pairs.end());
+    std::vector<uint32_t> route_off, riders(pairs.size()), small, big;
+    for (size_t i = 0; i < pairs.size(); ++i) {
+        if (i == 0 || pairs[i].first != pairs[i - 1].first) route_off.push_back((uint32_t)i);
+        riders[i] = pairs[i].second;
+    }
+    const uint32_t n_routes = (uint32_t)route_off.size();
+    route_off.push_back((uint32_t)pairs.size());
+    for (uint32_t r = 0; r < n_routes; ++r) (route_off[r + 1] - route_off[r] <= 64 ? small : big).push_back(r);
+
+    // ---- initial state: everyone Susceptible at home (citizen.rs:139-162), seeds Infected(0)
+    c->init_state.assign(N, (uint16_t)TE_SUSCEPTIBLE);
+    for (uint32_t i = 0; i < pop->n_seeds; ++i)
+        c->init_state[pop->seeds[i]] = (uint16_t)(TE_BIAS - (c->P.exposed_time + 1u));   // Infected(0) before step 1
+
+    free_device(c);
+    Dev &d = c->d;
+    std::memset(&d, 0, sizeof d);
+    d.n = N; d.n_global = n_global; d.id_base = pop->citizen_id_base; d.n_bld = B; d.n_room = R;
+    int rc;
+    if ((rc = dev_alloc(c, &d.state, N))) return rc;
+    if ((rc = dev_upload(c, &d.flags, fl.data(), N))) return rc;
+    if ((rc = dev_upload(c, &d.home, pop->home_building, N))) return rc;
+    if ((rc = dev_upload(c, &d.work, pop->work_building, N))) return rc;
+    if ((rc = dev_upload(c, &d.room, room_fixed.data(), N))) return rc;
+    uint32_t *cnt = nullptr;
+    if ((rc = dev_alloc(c, &cnt, (size_t)B + R))) return rc;
+    d.cnt_bld = cnt; d.cnt_room = cnt + B;
+    c->cnt_bytes = sizeof(uint32_t) * ((size_t)B + R);
+    uint64_t lut[512];
+    esim_threshold_lut(&c->P, lut);
+    if ((rc = dev_upload(c, &d.thr, lut, 512))) return rc;
+    if ((rc = dev_alloc(c, &d.ctrl, 1))) return rc;
+    if ((rc = dev_alloc(c, &d.records, (size_t)c->P.max_steps + 1))) return rc;
+    d.n_routes_small = (uint32_t)small.size(); d.n_routes_big = (uint32_t)big.size();
+    if ((rc = dev_upload(c, &d.route_small, small.data(), small.size()))) return rc;
+    if ((rc = dev_upload(c, &d.route_big, big.data(), big.size()))) return rc;
+    if ((rc = dev_upload(c, &d.route_off, route_off.data(), route_off.size()))) return rc;
+    if ((rc = dev_upload(c, &d.route_riders, riders.data(), riders.size()))) return rc;
+    const size_t big_scratch = big.empty() ? 0 : riders.size();
+    if ((rc = dev_alloc(c, &d.bus_key, big_scratch))) return rc;
+    if ((rc = dev_alloc(c, &d.bus_idx, big_scratch))) return rc;
+    if ((rc = dev_alloc(c, &d.bus_cnt, big_scratch))) return rc;
+    if ((rc = dev_alloc(c, &d.bus_flag, big_scratch))) return rc;
+    d.exposed_time = c->P.exposed_time; d.infected_time = c->P.infected_time;
+    d.vaccination_rate = c->P.vaccination_rate; d.bus_capacity = c->P.bus_capacity;
+    d.start_hour = c->P.start_hour; d.end_hour = c->P.end_hour;
+    d.seed_lo = (uint32_t)c->P.seed; d.seed_hi = (uint32_t)(c->P.seed >> 32);
+    d.thr_lockdown = c->P.lockdown_threshold; d.thr_vacc = c->P.vaccination_threshold;
+    d.thr_mask_pt = c->P.mask_pt_threshold; d.thr_mask_all = c->P.mask_everywhere_threshold;
+    d.max_steps = c->P.max_steps;
+    d.n_shards = sharded ? 2u : 1u;
+    d.n_shared_bld = pop->n_shared_buildings; d.n_shared_room = pop->n_shared_rooms;
+    if ((rc = dev_upload(c, &d.shared_bld, pop->shared_building_local, pop->n_shared_buildings))) return rc;
+    if ((rc = dev_upload(c, &d.shared_room, pop->shared_room_local, pop->n_shared_rooms))) return rc;
+    c->xa_n = XA_HEADER + (size_t)d.n_shared_bld + d.n_shared_room;
+    c->xb_n = XB_HEADER + VACC_BATCH / 32u;
+    if ((rc = dev_alloc(c, &d.xa, c->xa_n))) return rc;
+    if ((rc = dev_alloc(c, &d.xb, c->xb_n))) return rc;
+    HIP_TRY(c, hipMemset(d.xa, 0, sizeof(uint32_t) * c->xa_n));
+    HIP_TRY(c, hipMemset(d.xb, 0, sizeof(uint32_t) * c->xb_n));
+
+    c->grid_citizens = grid_for(N, TPB, 2048);
+    c->grid_bus_small = grid_for((size_t)d.n_routes_small * 64, TPB, 2048);
+    c->grid_bus_big = grid_for(d.n_routes_big, 1, 1024);
+    c->uploaded = true;
+    return esim_reset(ctx);
+}
+
+extern "C" int esim_reset(esim_ctx *ctx)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "esim_reset: no population uploaded");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    Ctrl h;
+    std::memset(&h, 0, sizeof h);
+    h.t = 1;
+    h.mask = ESIM_MASK_NONE;
+    HIP_TRY(c, hipMemcpy(c->d.ctrl, &h, sizeof h, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d.state, c->init_state.data(), sizeof(uint16_t) * c->d.n, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->d.cnt_bld, 0, c->cnt_bytes));
+    HIP_TRY(c, hipMemset(c->d.records, 0, sizeof(esim_step_result) * ((size_t)c->P.max_steps + 1)));
+    c->host_t = 1;
+    c->phase_s[0] = c->phase_s[1] = c->phase_s[2] = 0;
+    c->kev_used = 0;
+    return ESIM_OK;
+}
+
+namespace {
+
+int enqueue_begin(esim_ctx_impl *c, bool time_kernel)
+{
+    Dev &d = c->d;
+    if (c->phase_timing) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(c, hipMemsetAsync(d.cnt_bld, 0, c->cnt_bytes, c->stream));
+    if (time_kernel) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 0], c->stream));
+    hipLaunchKernelGGL(k_tick, dim3(c->grid_citizens), dim3(TPB), 0, c->stream, d);
+    if (time_kernel) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 1], c->stream));
+    if (d.n_shards > 1) {
+        const uint32_t n = (uint32_t)std::max<size_t>(XA_HEADER, std::max(d.n_shared_bld, d.n_shared_room));
+        hipLaunchKernelGGL(k_pack_a, dim3(grid_for(n, TPB, 1u << 20)), dim3(TPB), 0, c->stream, d);
+    }
+    if (c->phase_timing) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    return ESIM_OK;
+}
+
+int enqueue_exposures(esim_ctx_impl *c, bool time_kernel)
+{
+    Dev &d = c->d;
+    if (d.n_shards > 1) {
+        const uint32_t n = (uint32_t)std::max<size_t>(XA_HEADER, std::max(d.n_shared_bld, d.n_shared_room));
+        hipLaunchKernelGGL(k_unpack_a, dim3(grid_for(n, TPB, 1u << 20)), dim3(TPB), 0, c->stream, d);
+    }
+    if (time_kernel) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 2], c->stream));
+    hipLaunchKernelGGL(k_expose, dim3(c->grid_citizens), dim3(TPB), 0, c->stream, d);
+    if (time_kernel) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 3], c->stream));
+    if (d.n_routes_small) hipLaunchKernelGGL(k_bus_small, dim3(c->grid_bus_small), dim3(TPB), 0, c->stream, d);
+    if (d.n_routes_big) hipLaunchKernelGGL(k_bus_big, dim3(c->grid_bus_big), dim3(TPB), 0, c->stream, d);
+    if (d.n_shards > 1) hipLaunchKernelGGL(k_pack_b, dim3(VACC_BATCH / TPB), dim3(TPB), 0, c->stream, d);
+    if (c->phase_timing) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    return ESIM_OK;
+}
+
+int enqueue_finish(esim_ctx_impl *c)
+{
+    Dev &d = c->d;
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(FIN_TPB), 0, c->stream, d, d.n_shards > 1 ? 1 : 0);
+    if (c->phase_timing) {
+        HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+        HIP_TRY(c, hipEventSynchronize(c->ev[3]));
+        float ms;
+        for (int i = 0; i < 3; ++i) { HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1])); c->phase_s[i] += ms * 1e-3; }
+    }
+    c->host_t++;
+    HIP_TRY(c, hipGetLastError());
+    return ESIM_OK;
+}
+
+int check_budget(esim_ctx_impl *c, uint32_t n_steps)
+{
+    if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "no population uploaded");
+    if ((uint64_t)c->host_t + n_steps - 1 > c->P.max_steps)
+        return fail(c, ESIM_ERANGE, "step budget exhausted: max_steps reached (DiseaseModel::max_time_step)");
+    return ESIM_OK;
+}
+
+bool want_kernel_timing(esim_ctx_impl *c)
+{
+    if (!c->kernel_timing || (c->host_t % c->kernel_timing_stride) != 0) return false;
+    if (c->kev_used + 4 > c->kev.size()) {
+        for (int i = 0; i < 4; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return false; c->kev.push_back(e); }
+    }
+    return true;
+}
+
+int device_error(esim_ctx_impl *c)
+{
+    Ctrl h;
+    HIP_TRY(c, hipMemcpy(&h, c->d.ctrl, sizeof h, hipMemcpyDeviceToHost));
+    if (h.error) return fail(c, -(int)h.error, "device-side error (S underflow / vaccination window exhausted)");
+    return ESIM_OK;
+}
+
+}  // namespace
+
+extern "C" int esim_step_begin(esim_ctx *ctx)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    int rc = check_budget(c, 1);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    return enqueue_begin(c, false);
+}
+
+extern "C" int esim_step_exposures(esim_ctx *ctx)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "no population uploaded");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    return enqueue_exposures(c, false);
+}
+
+extern "C" int esim_step_finish(esim_ctx *ctx, esim_step_result *out)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "no population uploaded");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    int rc = enqueue_finish(c);
+    if (rc) return rc;
+    if (out) {
+        HIP_TRY(c, hipMemcpyAsync(out, &c->d.records[c->host_t - 1], sizeof *out, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return device_error(c);
+    }
+    return ESIM_OK;
+}
+
+extern "C" int esim_step(esim_ctx *ctx, esim_step_result *out)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    int rc = check_budget(c, 1);
+    if (rc) return rc;
+    if (c->d.n_shards > 1) return fail(c, ESIM_ESTATE, "esim_step: a sharded population needs the split-phase calls and an all-reduce");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    const bool tk = want_kernel_timing(c);
+    if ((rc = enqueue_begin(c, tk))) return rc;
+    if ((rc = enqueue_exposures(c, tk))) return rc;
+    if (tk) c->kev_used += 4;
+    return esim_step_finish(ctx, out);
+}
+
+extern "C" int esim_run(esim_ctx *ctx, uint32_t n_steps, int stop_when_done, esim_step_result *out_array, uint32_t *n_done)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    int rc = check_budget(c, n_steps);
+    if (rc) return rc;
+    if (c->d.n_shards > 1) return fail(c, ESIM_ESTATE, "esim_run: a sharded population needs the split-phase calls and an all-reduce");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    const uint32_t first = c->host_t;
+    const uint32_t flag = stop_when_done ? 1u : 0u;
+    HIP_TRY(c, hipMemcpyAsync(&c->d.ctrl->stop_when_done, &flag, sizeof flag, hipMemcpyHostToDevice, c->stream));
+    for (uint32_t s = 0; s < n_steps; ++s) {
+        const bool tk = want_kernel_timing(c);
+        if ((rc = enqueue_begin(c, tk))) return rc;
+        if ((rc = enqueue_exposures(c, tk))) return rc;
+        if (tk) c->kev_used += 4;
+        if ((rc = enqueue_finish(c))) return rc;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    Ctrl h;
+    HIP_TRY(c, hipMemcpy(&h, c->d.ctrl, sizeof h, hipMemcpyDeviceToHost));
+    if (h.error) return fail(c, -(int)h.error, "device-side error (S underflow / vaccination window exhausted)");
+    const uint32_t done = h.steps_done >= first ? h.steps_done - first + 1 : 0;
+    if (out_array && done)
+        HIP_TRY(c, hipMemcpy(out_array, &c->d.records[first], sizeof(esim_step_result) * done, hipMemcpyDeviceToHost));
+    if (n_done) *n_done = done;
+    return ESIM_OK;
+}
+
+extern "C" int esim_exchange_buffer(esim_ctx *ctx, int which, void **device_ptr, size_t *n_u32)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "no population uploaded");
+    if (which != 0 && which != 1) return fail(c, ESIM_EINVAL, "esim_exchange_buffer: which must be 0 or 1");
+    if (device_ptr) *device_ptr = which ? (void *)c->d.xb : (void *)c->d.xa;
+    if (n_u32) *n_u32 = which ? c->xb_n : c->xa_n;
+    return ESIM_OK;
+}
+
+extern "C" int esim_read_records(esim_ctx *ctx, uint32_t first_step, uint32_t n, esim_step_result *out)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "no population uploaded");
+    if (!out || first_step == 0 || (uint64_t)first_step + n > (uint64_t)c->P.max_steps + 1) return fail(c, ESIM_EINVAL, "esim_read_records: bad range");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, &c->d.records[first_step], sizeof(esim_step_result) * n, hipMemcpyDeviceToHost));
+    return device_error(c);
+}
+
+extern "C" int esim_stream(esim_ctx *ctx, void **stream)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !stream) return fail(c, ESIM_EINVAL, "esim_stream: null argument");
+    *stream = (void *)c->stream;
+    return ESIM_OK;
+}
+
+extern "C" int esim_synchronize(esim_ctx *ctx)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c) return ESIM_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ESIM_OK;
+}
+
+extern "C" int esim_download_state(esim_ctx *ctx, uint8_t *status, uint16_t *timer, uint32_t *current_building,
+                                   uint8_t *on_bus, uint8_t *eligible)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "no population uploaded");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    const uint32_t N = c->d.n;
+    uint8_t *d_status = nullptr, *d_bus = nullptr, *d_elig = nullptr; uint16_t *d_timer = nullptr; uint32_t *d_cur = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_status); (void)hipFree(d_bus); (void)hipFree(d_elig); (void)hipFree(d_timer); (void)hipFree(d_cur); };
+    const size_t n1 = N ? N : 1;
+    if ((status && hipMalloc(&d_status, n1) != hipSuccess) || (on_bus && hipMalloc(&d_bus, n1) != hipSuccess) ||
+        (eligible && hipMalloc(&d_elig, n1) != hipSuccess) || (timer && hipMalloc(&d_timer, 2 * n1) != hipSuccess) ||
+        (current_building && hipMalloc(&d_cur, 4 * n1) != hipSuccess)) { cleanup(); return fail(c, ESIM_ENOMEM, "esim_download_state: hipMalloc"); }
+    hipLaunchKernelGGL(k_decode_state, dim3(c->grid_citizens), dim3(TPB), 0, c->stream, c->d, d_status, d_timer, d_cur, d_bus, d_elig);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && status) e = hipMemcpy(status, d_status, N, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && on_bus) e = hipMemcpy(on_bus, d_bus, N, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && eligible) e = hipMemcpy(eligible, d_elig, N, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && timer) e = hipMemcpy(timer, d_timer, 2 * (size_t)N, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && current_building) e = hipMemcpy(current_building, d_cur, 4 * (size_t)N, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(c, ESIM_ENODEVICE, std::string("esim_download_state: ") + hipGetErrorString(e));
+    return ESIM_OK;
+}
+
+extern "C" int esim_enable_phase_timing(esim_ctx *ctx, int enable)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c) return ESIM_EINVAL;
+    c->phase_timing = enable != 0;
+    return ESIM_OK;
+}
+
+extern "C" int esim_phase_timings(esim_ctx *ctx, double out[4])
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !out) return ESIM_EINVAL;
+    out[0] = c->phase_s[0]; out[1] = c->phase_s[1]; out[2] = c->phase_s[2];
+    out[3] = out[0] + out[1] + out[2];
+    return ESIM_OK;
+}
+
+extern "C" int esim_enable_kernel_timing(esim_ctx *ctx, int enable)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c) return ESIM_EINVAL;
+    c->kernel_timing = enable > 0;
+    if (enable > 0) c->kernel_timing_stride = (uint32_t)enable;   // time every `enable`-th step
+    c->kev_used = 0;
+    return ESIM_OK;
+}
+
+extern "C" int esim_kernel_timings(esim_ctx *ctx, double out_ms[2], uint32_t *out_n)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !out_ms) return ESIM_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double a = 0, b = 0;
+    const size_t n = c->kev_used / 4;
+    for (size_t i = 0; i < n; ++i) {
+        float ms;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * i + 0], c->kev[4 * i + 1])); a += ms;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * i + 2], c->kev[4 * i + 3])); b += ms;
+    }
+    out_ms[0] = n ? a / n : 0.0; out_ms[1] = n ? b / n : 0.0;
+    if (out_n) *out_n = (uint32_t)n;
+    c->kev_used = 0;
+    return ESIM_OK;
+}

@@ -1,0 +1,50 @@
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
+// SC'11) -- the counter-based generator that replaces the reference's OS-seeded thread_rng
+// (sim/src/simulator.rs:342,630).  Shared by host code and HIP kernels of libesim.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ESIM_HD __host__ __device__ __forceinline__
+#else
+#define ESIM_HD static inline
+#endif
+
+struct philox_out { uint32_t w0, w1, w2, w3; };
+
+ESIM_HD uint32_t esim_mulhi32(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+ESIM_HD philox_out philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                 uint32_t k0, uint32_t k1)
+{
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = esim_mulhi32(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = esim_mulhi32(M1, c2), lo1 = M1 * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    philox_out o = { c0, c1, c2, c3 };
+    return o;
+}
+
+// 53-bit integer of the uniform draw for (citizen, step, slot): uniform = u53 * 2^-53.
+ESIM_HD uint64_t esim_u53(uint64_t seed, uint32_t citizen, uint32_t step, uint32_t slot)
+{
+    philox_out o = philox4x32_10(citizen, step, slot, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return (((uint64_t)o.w0 << 32) | o.w1) >> 11;
+}
+
+// draw slots (RNG contract)
+enum { ESIM_SLOT_HOME = 0, ESIM_SLOT_WORK = 1, ESIM_SLOT_BUS = 2, ESIM_SLOT_BUS_ORDER = 3,
+       ESIM_SLOT_VACCINE = 4, ESIM_SLOT_ROOM0 = 16 };

@@ -1,0 +1,165 @@
+"""Host-side mirror of the reference's `sim::simulator::Simulator` over libesim.
+
+Same names, argument meaning and side effects as the reference API that `run` and
+`visualisation` call (sim/src/simulator.rs):
+  Simulator.step()              -> bool      simulator.rs:131-152  (False = epidemic over)
+  Simulator.simulate(output)    -> None      simulator.rs:108-127  (progress print every 50 steps,
+                                             then the four JSON files of statistics.rs:113-150)
+The compute is the HIP library; this file only marshals.
+"""
+import ctypes as C
+import json
+import os
+import time
+
+import numpy as np
+
+from . import _lib
+from .population import Population
+
+DEBUG_ITERATION_PRINT = 50  # sim/src/config.rs:34
+
+
+class StatisticsRecorder:
+    """What `StatisticsRecorder` (sim/src/statistics.rs:97-204) keeps, filled from step results."""
+
+    def __init__(self):
+        self.global_stats = []       # StatisticEntry dicts, statistics.rs:208-215
+        self.timer_entries = []      # per step {"Generate Exposures":..,"Apply Exposures":..,"Apply Interventions":..,"total":..}
+        self.memory_usage_entries = []
+        self.exposures_all = []      # exposures per time step ("All" series, statistics.rs:119-136)
+
+    def push(self, rec, timings=None):
+        self.global_stats.append({k: rec[k] for k in
+                                  ("time_step", "susceptible", "exposed", "infected", "recovered", "vaccinated")})
+        self.exposures_all.append(rec["exposures_building"] + rec["exposures_bus"])
+        if timings is not None:
+            self.timer_entries.append(timings)
+        self.memory_usage_entries.append(_memory_usage())
+
+    def dump_to_file(self, directory):
+        """statistics.rs:113-150. `dump_to_file` calls next() first, which appends one all-zero
+        trailing StatisticEntry (Q14) -- reproduced so downstream notebooks see the same shape."""
+        os.makedirs(directory, exist_ok=True)          # fs::create_dir_all(directory), statistics.rs:116
+        stats = list(self.global_stats)
+        stats.append({"time_step": len(stats) + 1, "susceptible": 0, "exposed": 0, "infected": 0,
+                      "recovered": 0, "vaccinated": 0})
+        with open(directory + "exposures.json", "w") as f:
+            json.dump({"All": {"All": self.exposures_all}}, f)
+        with open(directory + "timings.json", "w") as f:
+            json.dump(self.timer_entries, f)
+        with open(directory + "memory.json", "w") as f:
+            json.dump(self.memory_usage_entries, f)
+        with open(directory + "global_stats.json", "w") as f:
+            json.dump(stats, f)
+
+
+def _memory_usage():
+    # config.rs:42-47 (VM size of the process, GB)
+    try:
+        with open("/proc/self/statm") as f:
+            pages = int(f.read().split()[0])
+        return "%.2f GB" % (pages * os.sysconf("SC_PAGE_SIZE") / 1024 / 1024 / 1024.0)
+    except OSError:
+        return "0.00 GB"
+
+
+class Simulator:
+    """`Simulator::from(builder)` (simulator.rs:601-644): takes a built population."""
+
+    def __init__(self, population, params=None, area_code="synthetic"):
+        self.lib = _lib.load()
+        self.area_code = area_code
+        self.population = population
+        self.params = params if params is not None else _lib.default_params()
+        self.current_population = population.n_citizens
+        self.statistics_recorder = StatisticsRecorder()
+        self._ctx = C.c_void_p()
+        _lib.check(self.lib.esim_create(C.byref(self.params), C.byref(self._ctx)))
+        ps = population.as_struct()
+        _lib.check(self.lib.esim_upload_population(self._ctx, C.byref(ps)), self._ctx)
+        self._steps = 0
+
+    # -- reference API -----------------------------------------------------------------
+    def step(self):
+        """Applies a single time step; returns False if the disease has finished."""
+        r = _lib.StepResult()
+        _lib.check(self.lib.esim_step(self._ctx, C.byref(r)), self._ctx)
+        self._steps += 1
+        rec = r.as_dict()
+        self.statistics_recorder.push(rec)
+        self.last = rec
+        return bool(rec["disease_exists"])
+
+    def simulate(self, output_name):
+        start = time.time()
+        max_time_step = int(self.params.max_steps)
+        for time_step in range(max_time_step):
+            if not self.step():
+                break
+            if time_step % DEBUG_ITERATION_PRINT == 0:
+                print("Completed %3d time steps, in: %6s seconds  Statistics: %s,   Memory usage: %s" % (
+                    DEBUG_ITERATION_PRINT, "%.2f" % (time.time() - start), self.last, _memory_usage()))
+                start = time.time()
+        self.statistics_recorder.dump_to_file(output_name)
+
+    # -- device-resident loop ----------------------------------------------------------
+    def run(self, n_steps, stop_when_done=False):
+        """`n_steps` of the loop of simulate() without host round trips; returns the records as a
+        structured numpy array (fields of esim_step_result)."""
+        buf = (_lib.StepResult * max(1, n_steps))()
+        n_done = C.c_uint32(0)
+        _lib.check(self.lib.esim_run(self._ctx, n_steps, int(stop_when_done), buf, C.byref(n_done)), self._ctx)
+        self._steps += n_done.value
+        arr = np.frombuffer(buf, dtype=RECORD_DTYPE, count=n_done.value).copy()
+        for i in range(n_done.value):
+            self.statistics_recorder.push({k: int(arr[k][i]) for k in arr.dtype.names})
+        return arr
+
+    def reset(self):
+        _lib.check(self.lib.esim_reset(self._ctx), self._ctx)
+        self.statistics_recorder = StatisticsRecorder()
+        self._steps = 0
+
+    def download_state(self):
+        n = self.population.n_citizens
+        out = {"status": np.zeros(n, np.uint8), "timer": np.zeros(n, np.uint16),
+               "current_building": np.zeros(n, np.uint32), "on_bus": np.zeros(n, np.uint8),
+               "eligible": np.zeros(n, np.uint8)}
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+        _lib.check(self.lib.esim_download_state(
+            self._ctx, p(out["status"], C.c_uint8), p(out["timer"], C.c_uint16),
+            p(out["current_building"], C.c_uint32), p(out["on_bus"], C.c_uint8),
+            p(out["eligible"], C.c_uint8)), self._ctx)
+        return out
+
+    def enable_kernel_timing(self, stride):
+        _lib.check(self.lib.esim_enable_kernel_timing(self._ctx, int(stride)), self._ctx)
+
+    def kernel_timings(self):
+        ms = (C.c_double * 2)()
+        n = C.c_uint32(0)
+        _lib.check(self.lib.esim_kernel_timings(self._ctx, ms, C.byref(n)), self._ctx)
+        return {"tick_ms": ms[0], "expose_ms": ms[1], "launches": n.value}
+
+    def enable_phase_timing(self, on=True):
+        _lib.check(self.lib.esim_enable_phase_timing(self._ctx, int(on)), self._ctx)
+
+    def phase_timings(self):
+        t = (C.c_double * 4)()
+        _lib.check(self.lib.esim_phase_timings(self._ctx, t), self._ctx)
+        return {"Generate Exposures": t[0], "Apply Exposures": t[1], "Apply Interventions": t[2], "total": t[3]}
+
+    def close(self):
+        if self._ctx:
+            self.lib.esim_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+RECORD_DTYPE = np.dtype([(n, np.uint32) for n in _lib.RECORD_FIELDS])

@@ -1,0 +1,209 @@
+/*
+ * esim.h -- C ABI of libesim: the MI355X (gfx950) implementation of the reference
+ * `sim` crate's per-timestep Citizen update loop.
+ *
+ * The reference (NoSuchThingAsRandom/EpidemicSimulator) has no FFI or plugin
+ * interface: its boundary for this path is the Rust API `Simulator::step` /
+ * `Simulator::simulate` (sim/src/simulator.rs:108,131).  Each entry point below names
+ * the reference item it replaces.  A Rust shim implementing `Simulator` over this ABI
+ * is shown in INTEGRATION.md.
+ *
+ * Conventions: every function returns ESIM_OK (0) or a negative ESIM_E* code and
+ * never unwinds across the boundary; esim_last_error() gives the text.  The caller
+ * owns every buffer it passes (the library copies in/out and retains no host
+ * pointer).  A context is used from one host thread at a time (the reference
+ * `Simulator` is !Send: it owns a ThreadRng, simulator.rs:102).  All compute runs
+ * on the GPU; there is no CPU fallback -- without a usable HIP device
+ * esim_create() fails with ESIM_ENODEVICE.
+ */
+#ifndef ESIM_H
+#define ESIM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESIM_OK          0
+#define ESIM_EINVAL     -1   /* bad argument / population contract violated */
+#define ESIM_ENODEVICE  -2   /* no HIP device / HIP runtime error */
+#define ESIM_ENOMEM     -3
+#define ESIM_ESTATE     -4   /* call out of order (e.g. step before upload) */
+#define ESIM_ERANGE     -5   /* step budget / encoding range exceeded */
+#define ESIM_ESIM       -6   /* the reference's own error path (S underflow, statistics.rs:275-287) */
+
+/* DiseaseStatus codes, sim/src/disease.rs:36-44 */
+enum { ESIM_SUSCEPTIBLE = 0, ESIM_EXPOSED = 1, ESIM_INFECTED = 2, ESIM_RECOVERED = 3, ESIM_VACCINATED = 4 };
+/* BuildingType, sim/src/models/building.rs:46-53 (only the three the builder creates) */
+enum { ESIM_HOUSEHOLD = 0, ESIM_WORKPLACE = 1, ESIM_SCHOOL = 2 };
+/* MaskStatus, sim/src/interventions.rs:26-30 */
+enum { ESIM_MASK_NONE = 0, ESIM_MASK_PUBLIC_TRANSPORT = 1, ESIM_MASK_EVERYWHERE = 2 };
+
+#define ESIM_NO_ROOM 0xFFFFFFFFu
+#define ESIM_FLAG_USES_PUBLIC_TRANSPORT 1u  /* Citizen::uses_public_transport, citizen.rs:132 */
+#define ESIM_FLAG_MASK_COMPLIANT        2u  /* Citizen::is_mask_compliant, citizen.rs:131 */
+
+/* Compile-time constants of the reference gathered into one runtime struct:
+ * DiseaseModel::covid() (sim/src/disease.rs:118-129), InterventionThresholds and
+ * MaskStatus::get_threshold (sim/src/interventions.rs:50-57,71-78), BUS_CAPACITY
+ * (sim/src/config.rs:37), start/end_working_hour (sim/src/models/citizen.rs:154-155). */
+typedef struct esim_params {
+    double   exposure_chance;            /* 0.00055 */
+    double   mask_effectiveness;         /* 0.70 */
+    double   lockdown_threshold;         /* 0.0034 */
+    double   vaccination_threshold;      /* 0.005 */
+    double   mask_pt_threshold;          /* 0.001 */
+    double   mask_everywhere_threshold;  /* 0.0022 */
+    uint32_t exposed_time;               /* 96 */
+    uint32_t infected_time;              /* 336 */
+    uint32_t vaccination_rate;           /* 1530 */
+    uint32_t bus_capacity;               /* 20 */
+    uint32_t start_hour;                 /* 9 */
+    uint32_t end_hour;                   /* 17 */
+    uint64_t seed;                       /* Philox4x32-10 key (replaces thread_rng, simulator.rs:630) */
+    int32_t  device;                     /* HIP device ordinal */
+    uint32_t max_steps;                  /* capacity of the device-side record log; DiseaseModel::max_time_step = 5000 */
+} esim_params;
+
+/* What SimulatorBuilder::build (sim/src/simulator_builder.rs:1162-1292) leaves behind,
+ * flattened to borrowed structure-of-arrays.  Citizens are indexed by
+ * CitizenID::global_index (citizen.rs:52-57), buildings by a dense index over all
+ * Output Areas (BuildingID, building.rs:62-67), rooms by a dense index over all
+ * School classes and offices (School::occupant_to_class, building.rs:341).
+ * Sharding (multi-GPU): a shard holds the citizens of a contiguous Output Area range;
+ * citizen_id_base / n_citizens_global keep the Philox counters global, and the
+ * shared_* tables name the buildings / rooms whose members live on several shards. */
+typedef struct esim_population {
+    uint32_t n_citizens, n_buildings, n_areas, n_rooms, n_seeds;
+    uint32_t citizen_id_base;        /* global index of local citizen 0 (0 when unsharded) */
+    uint32_t n_citizens_global;      /* == n_citizens when unsharded */
+    uint32_t n_shared_buildings;     /* 0 when unsharded */
+    uint32_t n_shared_rooms;         /* 0 when unsharded */
+    const uint32_t *home_building;   /* [n_citizens] Citizen::household_code, citizen.rs:116 */
+    const uint32_t *work_building;   /* [n_citizens] Citizen::workplace_code (== home when none), citizen.rs:118 */
+    const uint32_t *room;            /* [n_citizens] class/office of a school member, else ESIM_NO_ROOM */
+    const uint8_t  *flags;           /* [n_citizens] ESIM_FLAG_* */
+    const uint16_t *age;             /* [n_citizens] or NULL -- carried for API fidelity, never read per step */
+    const uint8_t  *occupation;      /* [n_citizens] or NULL -- idem (simulator_builder.rs:296-300) */
+    const uint32_t *building_area;   /* [n_buildings] OutputAreaID::index of the building, building.rs:63 */
+    const uint8_t  *building_type;   /* [n_buildings] ESIM_HOUSEHOLD/WORKPLACE/SCHOOL */
+    const uint32_t *room_building;   /* [n_rooms] the School each room belongs to */
+    const uint32_t *seeds;           /* [n_seeds] local indices starting Infected(0), simulator_builder.rs:1111-1140 */
+    const int32_t  *shared_building_local; /* [n_shared_buildings] local building index or -1 */
+    const int32_t  *shared_room_local;     /* [n_shared_rooms] local room index or -1 */
+} esim_population;
+
+/* One StatisticEntry (sim/src/statistics.rs:208-215) plus what the step decided. */
+typedef struct esim_step_result {
+    uint32_t time_step, susceptible, exposed, infected, recovered, vaccinated;
+    uint32_t exposures_building;     /* successful Citizen::expose calls via buildings, simulator.rs:337-345 */
+    uint32_t exposures_bus;          /* ... via PublicTransport, simulator.rs:436-446 */
+    uint32_t lockdown;               /* InterventionStatus::lockdown_enabled() after this step */
+    uint32_t vaccination_active;     /* vaccination_program_started() after this step */
+    uint32_t mask_status;            /* ESIM_MASK_* after this step */
+    uint32_t n_riders;               /* citizens on public transport this step */
+    uint32_t vaccinated_now;         /* citizens set Vaccinated at the end of this step, simulator.rs:524-553 */
+    uint32_t eligible_count;         /* |citizens_eligible_for_vaccine| after this step */
+    uint32_t disease_exists;         /* StatisticsRecorder::disease_exists(), statistics.rs:289-291 */
+    uint32_t reserved;
+} esim_step_result;
+
+typedef struct esim_ctx esim_ctx;
+
+/* DiseaseModel::covid() + Default for InterventionThresholds/InterventionStatus. */
+void esim_default_params(esim_params *p);
+
+/* Replaces Simulator::from(SimulatorBuilder) (simulator.rs:601-644): creates the device
+ * context; esim_upload_population copies the population to HBM and builds the derived
+ * tables (route lists, probability-threshold LUT). */
+int  esim_create(const esim_params *p, esim_ctx **out);
+int  esim_upload_population(esim_ctx *ctx, const esim_population *pop);
+/* Back to time step 0 with the uploaded population (all Susceptible, seeds Infected(0)). */
+int  esim_reset(esim_ctx *ctx);
+
+/* Replaces Simulator::step (simulator.rs:131-152).  out->disease_exists == 0 is the
+ * reference's Ok(false). */
+int  esim_step(esim_ctx *ctx, esim_step_result *out);
+/* Replaces the loop of Simulator::simulate (simulator.rs:114-123): runs up to n_steps on the
+ * device without host round trips; stops early when the disease is gone iff stop_when_done.
+ * out_array has room for n_steps entries; *n_done receives the number written. */
+int  esim_run(esim_ctx *ctx, uint32_t n_steps, int stop_when_done,
+              esim_step_result *out_array, uint32_t *n_done);
+
+/* Split-phase form of one step for sharded (multi-GPU) runs.  Between the phases the
+ * caller SUM-all-reduces the exchange buffer (device memory, uint32) across shards:
+ *   esim_step_begin     -- Citizen::execute_time_step for every citizen (generate_exposures,
+ *                          simulator.rs:155-260); packs counts + shared infected counts
+ *   [all-reduce A]
+ *   esim_step_exposures -- apply_exposures (simulator.rs:262-405); packs vaccination liveness
+ *   [all-reduce B]
+ *   esim_step_finish    -- apply_interventions (simulator.rs:455-556), writes the record
+ * With one shard the buffers need no reduction and esim_step() is exactly this sequence. */
+int  esim_step_begin(esim_ctx *ctx);
+int  esim_step_exposures(esim_ctx *ctx);
+int  esim_step_finish(esim_ctx *ctx, esim_step_result *out /* may be NULL */);
+int  esim_exchange_buffer(esim_ctx *ctx, int which /* 0 = A, 1 = B */, void **device_ptr, size_t *n_u32);
+/* Record log read-back for split-phase runs (records first..first+n-1, 1-based time steps). */
+int  esim_read_records(esim_ctx *ctx, uint32_t first_step, uint32_t n, esim_step_result *out);
+/* The HIP stream all work of this context is enqueued on (hipStream_t as void*). */
+int  esim_stream(esim_ctx *ctx, void **stream);
+int  esim_synchronize(esim_ctx *ctx);
+
+/* Per-citizen state in reference terms, for visualisation / lookup-table sync / checkpoints
+ * (replaces reading Simulator.output_areas[..].citizens, run/src/main.rs:246-259,
+ * visualisation/src/citizen_connections.rs:40-62).  Any pointer may be NULL.
+ *   status  ESIM_* code           (Citizen::disease_status)
+ *   timer   Exposed(t)/Infected(t) payload, 0 otherwise
+ *   current_building               (Citizen::current_building_position)
+ *   on_bus  0 None, 1 (home OA, work OA), 2 (work OA, home OA)   (Citizen::on_public_transport)
+ *   eligible member of Simulator::citizens_eligible_for_vaccine  (simulator.rs:97) */
+int  esim_download_state(esim_ctx *ctx, uint8_t *status, uint16_t *timer,
+                         uint32_t *current_building, uint8_t *on_bus, uint8_t *eligible);
+
+/* GPU time per phase since the last reset, seconds, in the reference's timer labels
+ * (simulator.rs:137,140,143; statistics.rs:138-140):
+ *   out[0] "Generate Exposures", out[1] "Apply Exposures", out[2] "Apply Interventions", out[3] total.
+ * Only measured while phase timing is enabled (it inserts events between phases). */
+int  esim_enable_phase_timing(esim_ctx *ctx, int enable);
+int  esim_phase_timings(esim_ctx *ctx, double out[4]);
+
+/* Mean duration (ms) of the dominant per-citizen kernels over the launches since the last
+ * call, measured with hipEvents on the context's stream when kernel timing is enabled.
+ *   out_ms[0] tick kernel, out_ms[1] exposure kernel; out_n = launches averaged. */
+int  esim_enable_kernel_timing(esim_ctx *ctx, int enable);
+int  esim_kernel_timings(esim_ctx *ctx, double out_ms[2], uint32_t *out_n);
+
+const char *esim_last_error(const esim_ctx *ctx);   /* ctx may be NULL: last esim_create error */
+void esim_destroy(esim_ctx *ctx);
+
+/* The exposure-probability LUT the kernels use: thresholds[mask][n & 255] =
+ * ceil(q * 2^53) with q = 1 - (1 - p_eff)^(n as u8) (citizen.rs:47-49,239;
+ * disease.rs:131-154).  mask 0: p_eff = p, mask 1: p_eff = p - p*mask_effectiveness.
+ * Pure host arithmetic; exported so parity tests can pin it. */
+int  esim_threshold_lut(const esim_params *p, uint64_t out[512]);
+
+/* ---- synthetic populations: stands in for load_census_data + osm_data +
+ * SimulatorBuilder, whose inputs are not available.  Pure host code. ---- */
+typedef struct esim_synth_spec {
+    uint32_t n_citizens, n_areas, citizens_per_school, n_seeds;
+    uint64_t seed;
+    double   area_jitter;     /* per-area population = mean * (1 +- jitter) */
+    double   p_public_transport, p_mask_compliant, p_work_from_home, p_teaching;
+} esim_synth_spec;
+/* presets: "york", "yh_census", "syn3m5", "uk64m"  */
+int  esim_synth_preset(const char *name, esim_synth_spec *out);
+/* Allocates the arrays of *out (shared_* left empty); release with esim_synth_free. */
+int  esim_synth_create(const esim_synth_spec *spec, esim_population *out);
+void esim_synth_free(esim_population *pop);
+/* Cuts the shard of Output Areas [area_begin, area_end) out of a whole population:
+ * citizens living there, every building/room they reference (remote ones become ghosts),
+ * and shared tables laid out identically on every shard of the same `cuts`
+ * (cuts[0..n_shards] are the area boundaries of all shards).  Release with esim_synth_free. */
+int  esim_shard_population(const esim_population *whole, const uint32_t *cuts, uint32_t n_shards,
+                           uint32_t shard, esim_population *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,105 @@
+"""The C-ABI library loads and exports every symbol include/esim.h declares; host-only entry points
+(LUT, synthetic populations, sharding) work without a GPU; compute entry points fail loudly
+without one (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from epidemicsimulator_amd import Population, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "esim.h")).read()
+    return sorted(set(re.findall(r"\b(esim_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_lib.StepResult) == 64
+    assert C.sizeof(_lib.Params) == 6 * 8 + 6 * 4 + 8 + 4 + 4
+    assert C.sizeof(_lib.SynthSpec) == 16 + 8 + 5 * 8
+
+
+def test_default_params_are_the_reference_constants():
+    p = _lib.default_params()
+    assert (p.exposure_chance, p.mask_effectiveness) == (0.00055, 0.70)          # disease.rs:120,127
+    assert (p.exposed_time, p.infected_time, p.vaccination_rate) == (96, 336, 1530)  # disease.rs:122-125
+    assert (p.lockdown_threshold, p.vaccination_threshold) == (0.0034, 0.005)    # interventions.rs:74-75
+    assert (p.mask_pt_threshold, p.mask_everywhere_threshold) == (0.001, 0.0022)
+    assert (p.bus_capacity, p.start_hour, p.end_hour, p.max_steps) == (20, 9, 17, 5000)
+
+
+def test_synthetic_york_shape():
+    pop = Population.synthetic("york")
+    assert pop.n_citizens == 197603 and pop.n_areas == 637
+    bt = pop.building_type
+    assert (bt == _lib.SCHOOL).sum() == 25
+    students = (pop.occupation == 9).mean()
+    assert 0.17 < students < 0.22                                     # Appendix B: 18-20 %
+    assert 0.18 < (pop.flags & 1).mean() < 0.22                       # config.rs:36
+    assert 0.78 < ((pop.flags >> 1) & 1).mean() < 0.82                # disease.rs:126
+    wfh = (pop.home_building == pop.work_building).mean()
+    assert 0.09 < wfh < 0.14                                          # Appendix B: 10.8-12.5 %
+    # Q11: every non-school worker works in the home area
+    non_school = bt[pop.work_building] != _lib.SCHOOL
+    assert (pop.building_area[pop.work_building][non_school] == pop.building_area[pop.home_building][non_school]).all()
+    # every school member has a room of that school
+    sch = ~non_school
+    assert (pop.room_building[pop.room[sch]] == pop.work_building[sch]).all()
+    # citizens are ordered by home area, households are contiguous
+    assert (np.diff(pop.home_building.astype(np.int64)) >= 0).all()
+    # deterministic
+    again = Population.synthetic("york")
+    assert (again.work_building == pop.work_building).all() and (again.seeds == pop.seeds).all()
+
+
+def test_sharding_covers_the_population():
+    pop = Population.synthetic("york", n_citizens=20000, n_areas=64, citizens_per_school=2500)
+    cuts = pop.even_cuts(3)
+    shards = [pop.shard(cuts, i) for i in range(3)]
+    assert sum(s.n_citizens for s in shards) == pop.n_citizens
+    assert [s.citizen_id_base for s in shards] == list(np.cumsum([0] + [s.n_citizens for s in shards[:-1]]))
+    assert all(s.n_citizens_global == pop.n_citizens for s in shards)
+    # shared tables have identical length on every shard and each entry is local on >= 2 shards
+    nb, nr = shards[0].n_shared_buildings, shards[0].n_shared_rooms
+    assert all(s.n_shared_buildings == nb and s.n_shared_rooms == nr for s in shards)
+    assert nb > 0 and nr > 0
+    present = sum((s.shared_building_local >= 0).astype(int) for s in shards)
+    assert (present >= 2).all()
+    for s in shards:                                                  # round trip of static fields
+        lo = s.citizen_id_base
+        assert (pop.flags[lo:lo + s.n_citizens] == s.flags).all()
+        assert (pop.building_area[pop.work_building[lo:lo + s.n_citizens]] == s.building_area[s.work_building]).all()
+    assert sum(s.n_seeds for s in shards) == pop.n_seeds
+
+
+def test_compute_fails_loudly_without_gpu(has_gpu):
+    if has_gpu:
+        pytest.skip("GPU present")
+    lib = _lib.load()
+    p = _lib.default_params()
+    ctx = C.c_void_p()
+    rc = lib.esim_create(C.byref(p), C.byref(ctx))
+    assert rc == -2                                                   # ESIM_ENODEVICE: no CPU fallback
+    assert b"HIP" in lib.esim_last_error(None)
+
+
+def test_create_rejects_out_of_range_params(has_gpu):
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    assert lib.esim_create(C.byref(_lib.default_params(exposed_time=400, infected_time=200)), C.byref(ctx)) == -5
+    assert lib.esim_create(C.byref(_lib.default_params(max_steps=9000)), C.byref(ctx)) == -5
+    assert lib.esim_create(C.byref(_lib.default_params(bus_capacity=0)), C.byref(ctx)) == -1

@@ -1,0 +1,216 @@
+"""Pins the CPU oracle to every known answer the reference offers for this path.
+
+The reference has no tests or golden vectors for Simulator::step, so these are the pins:
+Philox KATs (Random123), the f64 exposure-probability bit patterns of citizen.rs:47-49 with host
+libm, timer windows of disease.rs:47-71 (cross-checked with logs/pc_logs/v1.6/york.log:489-490 --
+recovered 0 at step 301, >0 at step 351), schedule hours, intervention thresholds, conservation.
+"""
+import ctypes as C
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import _oracle
+from epidemicsimulator_amd import Population, _lib
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bits(x):
+    return struct.unpack("<Q", struct.pack("<d", x))[0]
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors, philox4x32 10 rounds
+    kats = [
+        ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+        ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+        ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+    ]
+    L = _oracle.lib()
+    for ctr, key, want in kats:
+        c, k, o = (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), (C.c_uint32 * 4)()
+        L.orc_philox4x32_10(c, k, o)
+        assert list(o) == want
+
+
+def test_exposure_probability_bit_patterns():
+    # exact f64 bit patterns, p = 0.00055, masked p = p - p*0.7
+    L = _oracle.lib()
+    p = 0.00055
+    pm = p - p * 0.7
+    assert repr(pm) == "0.00016500000000000005"
+    want = {1: 0x3f4205bc01a37000, 2: 0x3f52047733125200, 10: 0x3f7678ea48d5ed80, 255: 0x3fc0c116cc5034d4}
+    for n, b in want.items():
+        assert bits(L.orc_binomial(p, n)) == b
+    assert L.orc_binomial(p, 0) == 0.0
+    prm = _oracle.default_params()
+    # `as u8` truncation (citizen.rs:239): q(256) = 0, q(257) = q(1), q(1100) = q(76)
+    assert L.orc_q(C.byref(prm), 256, 1, 0) == 0.0
+    assert bits(L.orc_q(C.byref(prm), 257, 1, 0)) == want[1]
+    assert bits(L.orc_q(C.byref(prm), 1100, 1, 0)) == 0x3fa4f753b154d3e0
+    assert bits(L.orc_binomial(pm, 1)) == 0x3f25a07b352a8000
+    assert bits(L.orc_binomial(pm, 255)) == 0x3fa518e1d27547f0
+    # Q7: the reduced probability only reaches NON-compliant citizens under MaskStatus::Everywhere
+    assert bits(L.orc_q(C.byref(prm), 1, 0, 2)) == 0x3f25a07b352a8000
+    assert bits(L.orc_q(C.byref(prm), 1, 1, 2)) == want[1]
+    assert bits(L.orc_q(C.byref(prm), 1, 0, 1)) == want[1]
+
+
+def test_exposure_chance_matches_reference_formula():
+    L = _oracle.lib()
+    prm = _oracle.default_params()
+    p = 0.00055
+    assert L.orc_exposure_chance(C.byref(prm), 0, 0, 0) == p
+    assert L.orc_exposure_chance(C.byref(prm), 0, 1, 0) == p
+    assert L.orc_exposure_chance(C.byref(prm), 0, 1, 1) == p - p * 0.7
+    assert L.orc_exposure_chance(C.byref(prm), 0, 2, 0) == p - p * 0.7
+    assert L.orc_exposure_chance(C.byref(prm), 1, 0, 0) == 0.0      # vaccinated: negative -> 0
+
+
+def test_library_lut_equals_oracle_probabilities():
+    """The integer thresholds libesim uploads are ceil(q*2^53) of the oracle's f64 q."""
+    import math
+    lib = _lib.load()
+    lut = (C.c_uint64 * 512)()
+    ep = _lib.default_params()
+    assert lib.esim_threshold_lut(C.byref(ep), lut) == 0
+    L = _oracle.lib()
+    prm = _oracle.params_from_esim(ep)
+    for row, (compliant, mask) in enumerate(((1, 0), (0, 2))):
+        for n in range(256):
+            q = L.orc_q(C.byref(prm), n, compliant, mask)
+            assert lut[row * 256 + n] == math.ceil(math.ldexp(q, 53))
+    # u < q  <=>  u53 < threshold, checked on the two integers around each threshold
+    for n in (1, 2, 10, 255):
+        thr = lut[n]
+        q = L.orc_q(C.byref(prm), n, 1, 0)
+        assert (thr - 1) * 2.0 ** -53 < q and not (thr * 2.0 ** -53 < q)
+
+
+def tiny_world(n_homes=3, per_home=2, **flags):
+    """n_homes households in one area, nobody works."""
+    n = n_homes * per_home
+    home = np.repeat(np.arange(n_homes, dtype=np.uint32), per_home)
+    return Population(home_building=home, work_building=home.copy(), flags=np.full(n, flags.get("flags", 0), np.uint8),
+                      building_area=np.zeros(n_homes, np.uint32), building_type=np.zeros(n_homes, np.uint8),
+                      seeds=np.array([0], np.uint32), n_areas=1)
+
+
+def test_timer_windows_of_a_seed():
+    # A seed is Infected(0) before any tick => I in records 1..336, R from 337
+    pop = tiny_world()
+    prm = _oracle.default_params(exposure_chance=0.0)
+    rec = _oracle.Oracle(pop, prm).run(400)
+    inf = rec["infected"]
+    assert (inf[:336] == 1).all() and (inf[336:] == 0).all()
+    assert rec["recovered"][335] == 0 and rec["recovered"][336] == 1
+    assert rec["time_step"][0] == 1                                   # Q1: first processed hour is 1
+
+
+def test_timer_windows_of_an_exposure():
+    # exposed in step t => E in records t..t+96 (97), I in t+97..t+433 (337), R from t+434
+    pop = tiny_world(n_homes=1, per_home=2)
+    prm = _oracle.default_params(exposure_chance=1.0)                 # q = 1: certain exposure in step 1
+    rec = _oracle.Oracle(pop, prm).run(500)
+    t = 1
+    assert rec["exposures_building"][0] == 1
+    e = rec["exposed"]
+    assert (e[t - 1:t + 96] == 1).all() and e[t + 96] == 0
+    i_other = rec["infected"] - (rec["time_step"] <= 336)             # subtract the seed
+    assert (i_other[t + 96:t + 433] == 1).all() and i_other[t + 433] == 0 and i_other[t + 95] == 0
+    assert rec["recovered"][t + 433] == 2
+
+
+def test_schedule_hours_and_bus_riders():
+    # work position from hour%24 == 9 to 16, bus flag at 8 and 16 for users of public transport
+    pop = tiny_world(flags=_lib.FLAG_USES_PUBLIC_TRANSPORT)
+    # (1 seed in 6 citizens is far over the lockdown threshold, which would freeze the schedule: Q8)
+    o = _oracle.Oracle(pop, _oracle.default_params(exposure_chance=0.0, lockdown_threshold=2.0))
+    seen = {}
+    for step in range(1, 49):
+        r = o.step()
+        seen[step] = (int(r["n_riders"]), o.state())
+    for step, (riders, st) in seen.items():
+        h = step % 24
+        assert riders == (pop.n_citizens if h in (8, 16) else 0)
+        want_bus = 1 if h == 8 else (2 if h == 16 else 0)
+        assert (st["on_bus"] == want_bus).all()
+        assert (st["current_building"] == pop.home_building).all()      # nobody has a workplace here
+
+
+def test_lockdown_freezes_the_schedule():
+    # Q8: the flag decided at the end of step t-1 freezes positions and bus flags in step t
+    n = 400
+    home = np.arange(n, dtype=np.uint32) // 2
+    work = np.full(n, n // 2, np.uint32)                                # one workplace for everybody
+    pop = Population(home_building=home, work_building=work, flags=np.full(n, 1, np.uint8),
+                     building_area=np.zeros(n // 2 + 1, np.uint32),
+                     building_type=np.array([0] * (n // 2) + [1], np.uint8), seeds=np.array([0, 1], np.uint32), n_areas=1)
+    # x = 2/400 = 0.005 > 0.0034 from step 1 on => lockdown in force from step 2, nobody ever moves
+    o = _oracle.Oracle(pop, _oracle.default_params(exposure_chance=0.0, vaccination_threshold=2.0))
+    rec = o.run(30)
+    assert rec["lockdown"].tolist() == [1] * 30
+    assert (rec["n_riders"] == 0).all()
+    assert (o.state()["current_building"] == home).all()
+
+
+def test_intervention_thresholds_are_strict():
+    # 1000 citizens, k seeds => x = k/1000 exactly at the thresholds must NOT trigger (strict <)
+    n = 1000
+    home = np.arange(n, dtype=np.uint32)
+
+    def run(k):
+        pop = Population(home_building=home, work_building=home.copy(), flags=np.zeros(n, np.uint8),
+                         building_area=np.zeros(n, np.uint32), building_type=np.zeros(n, np.uint8),
+                         seeds=np.arange(k, dtype=np.uint32), n_areas=1)
+        prm = _oracle.default_params(exposure_chance=0.0, lockdown_threshold=0.004, vaccination_threshold=0.006,
+                                     mask_pt_threshold=0.001, mask_everywhere_threshold=0.002)
+        return _oracle.Oracle(pop, prm).run(3)
+    r = run(1)          # x = 0.001: not > 0.001
+    assert r["mask_status"].tolist() == [0, 0, 0]
+    r = run(2)          # x = 0.002: PT at step 1, not Everywhere (0.002 < x false)
+    assert r["mask_status"].tolist() == [1, 1, 1]
+    r = run(3)          # one level per step: None -> PT -> Everywhere
+    assert r["mask_status"].tolist() == [1, 2, 2]
+    assert run(4)["lockdown"].tolist() == [0, 0, 0]
+    assert run(5)["lockdown"].tolist() == [1, 1, 1]
+    assert run(6)["vaccination_active"].tolist() == [0, 0, 0]
+    r = run(7)
+    assert r["vaccination_active"].tolist() == [1, 1, 1]
+    # eligible = susceptible at the trigger; all 993 <= 1530 are vaccinated in the same call (Q10)
+    assert r["vaccinated_now"][0] == 993 and r["vaccinated"][0] == 0 and r["vaccinated"][1] == 993
+
+
+def test_conservation_and_record_shape_york_100():
+    pop = Population.synthetic("york")
+    rec = _oracle.Oracle(pop).run(100)
+    tot = rec["susceptible"] + rec["exposed"] + rec["infected"] + rec["recovered"] + rec["vaccinated"]
+    assert (tot == pop.n_citizens).all()                              # statistics.rs:248-250
+    assert rec["infected"][0] == len(set(pop.seeds.tolist()))
+
+
+def test_oracle_golden_trajectory_fixture():
+    """Oracle output on a small seeded world is frozen as a fixture (tests/golden/make_golden.py)."""
+    with open(os.path.join(GOLDEN, "oracle_small_world.json")) as f:
+        g = json.load(f)
+    pop = Population.synthetic("york", **g["spec"])
+    prm = _oracle.default_params(**g["params"])
+    rec = _oracle.Oracle(pop, prm).run(g["steps"])
+    for k, want in g["records"].items():
+        assert rec[k].tolist() == want, k
+
+
+def test_reference_envelope_fixture_is_consistent():
+    """Distributional envelope from the reference's recorded York run (v1.7.1): not bit-exact, only
+    the facts the reference's own output shows."""
+    with open(os.path.join(GOLDEN, "reference_york_v171_envelope.json")) as f:
+        env = json.load(f)
+    assert env["n_citizens"] == 197603
+    assert env["first_step_over"]["0.001"] < env["first_step_over"]["0.0022"] < env["first_step_over"]["0.0034"] \
+        < env["first_step_over"]["0.005"]
+    assert env["recovered_decreases"] is True                       # Q10: vaccination relabels R
