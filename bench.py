@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""bench.py -- citizen-timesteps/sec of the per-timestep Citizen update loop on MI355X.
+
+A "step" is one time step (Simulator::step, sim/src/simulator.rs:131) over the whole synthetic
+population.  Workload: BASELINE.json configs[4], the 64 M-citizen synthetic UK (preset `uk64m`,
+interventions enabled) -- it fits one GPU, so N=1 runs all of it and N>1 shards the same population by
+Output Area (strong scaling), one process per GPU, two small SUM all-reduces per step over RCCL.
+Population build and upload are outside the timed region; inputs are resident in HBM when it starts.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_CITIZEN_STEP = 26.0      # state R+W 4, flags 2, home/work/room ids 12, two count gathers 8
+ALGO_BYTES_TICK, ALGO_BYTES_EXPOSE = 4.0, 22.0   # how the 26 B split over the two per-citizen kernels
+HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def cpu_baseline(pop, params, steps):
+    """The CPU oracle (oracle/esim_oracle.c, single thread) timed on this host on the first `steps`
+    time steps of the same population.  A reported baseline, not the thing measured."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle
+    orc = _oracle.Oracle(pop, _oracle.params_from_esim(params))
+    t0 = time.perf_counter()
+    rec = orc.run(steps)
+    dt = time.perf_counter() - t0
+    orc.close()
+    return {"value": pop.n_citizens * len(rec) / dt, "unit": "citizen-timesteps/s", "cores": 1, "kind": "port",
+            "sample": "first %d time steps of the same %d-citizen population, single-thread oracle/esim_oracle.c, %.1f s"
+                      % (len(rec), pop.n_citizens, dt)}, rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--preset", default="uk64m", help="synthetic population preset (default: the benchmark workload)")
+    ap.add_argument("--cpu-steps", type=int, default=24, help="time steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--timing-stride", type=int, default=16, help="bracket the per-citizen kernels with HIP events every n-th step")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from epidemicsimulator_amd import Population, _lib
+    from epidemicsimulator_amd.distributed import ShardedSimulator
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    steps, warmup = args.steps, min(args.warmup, args.steps)
+    pop = Population.synthetic(args.preset)
+    params = _lib.default_params(max_steps=max(steps, warmup, 1))
+    sim = ShardedSimulator(pop, rank, world, params, device_index=local_rank)
+
+    def fence():
+        sim.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    # W untimed warm-up steps, then back to time step 0 so the timed region is steps 1..K of the workload
+    sim.run(warmup)
+    fence()
+    sim.reset()
+    sim.enable_kernel_timing(args.timing_stride)
+    fence()
+    t0 = time.perf_counter()
+    sim.run(steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kt = sim.kernel_timings()
+    rec = sim.records(1, steps)
+
+    if rank == 0:
+        n_total = pop.n_citizens
+        n_local = sim.population.n_citizens
+        value = n_total * steps / elapsed
+        dom = "expose" if kt["expose_ms"] >= kt["tick_ms"] else "tick"
+        dom_ms = kt[dom + "_ms"]
+        dom_bytes = (ALGO_BYTES_EXPOSE if dom == "expose" else ALGO_BYTES_TICK) * n_local
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("workload") == args.preset and tj.get("n_gpus") == world:
+                traffic = tj.get("k_" + dom + "_bytes_per_launch")
+        out = {
+            "metric": "citizen-timesteps/sec", "value": value, "unit": "citizen-timesteps/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u16/u32 state, u64 Philox thresholds",
+            "data": "synthetic",
+            "config": {"workload": "%s: %d citizens, %d Output Areas, %d steps, interventions on; Output Areas sharded over %d GPU(s)"
+                                   % (args.preset, n_total, pop.n_areas, steps, world),
+                       "citizens_per_gpu": n_local, "seed": int(params.seed)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_" + dom,
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms, "launches_timed": kt["launches"],
+                         "other_kernels": {"k_tick_ms": kt["tick_ms"], "k_expose_ms": kt["expose_ms"]},
+                         "whole_step_algorithmic_GBs": ALGO_BYTES_PER_CITIZEN_STEP * n_total * steps / elapsed / 1e9},
+            "final_record": {k: int(rec[k][-1]) for k in ("time_step", "susceptible", "exposed", "infected", "recovered", "vaccinated")},
+        }
+        if world == 1 and args.cpu_steps > 0:
+            cb, orc_rec = cpu_baseline(pop, params, min(args.cpu_steps, steps))
+            out["cpu_baseline"] = cb
+            for f in ("susceptible", "exposed", "infected", "recovered", "vaccinated"):
+                if not (orc_rec[f] == rec[f][:len(orc_rec)]).all():
+                    raise SystemExit("bench: GPU records differ from the CPU oracle in field %s" % f)
+            out["cpu_baseline"]["records_match_gpu"] = True
+        print(json.dumps(out))
+    sim.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,7 +82,8 @@ class SynthSpec(C.Structure):
 SYMBOLS = [
     "esim_default_params", "esim_create", "esim_upload_population", "esim_reset", "esim_step",
     "esim_run", "esim_step_begin", "esim_step_exposures", "esim_step_finish",
-    "esim_exchange_buffer", "esim_read_records", "esim_stream", "esim_synchronize",
+    "esim_exchange_buffer", "esim_read_records", "esim_stream", "esim_set_stream",
+    "esim_set_exchange_buffer", "esim_synchronize",
     "esim_download_state", "esim_enable_phase_timing", "esim_phase_timings",
     "esim_enable_kernel_timing", "esim_kernel_timings", "esim_last_error", "esim_destroy",
     "esim_threshold_lut", "esim_synth_preset", "esim_synth_create", "esim_synth_free",
@@ -116,6 +117,8 @@ def load():
         "esim_exchange_buffer": (C.c_int, [vp, C.c_int, pvp, C.POINTER(C.c_size_t)]),
         "esim_read_records": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(StepResult)]),
         "esim_stream": (C.c_int, [vp, pvp]),
+        "esim_set_stream": (C.c_int, [vp, vp]),
+        "esim_set_exchange_buffer": (C.c_int, [vp, C.c_int, vp]),
         "esim_synchronize": (C.c_int, [vp]),
         "esim_download_state": (C.c_int, [vp, _u8p, _u16p, _u32p, _u8p, _u8p]),
         "esim_enable_phase_timing": (C.c_int, [vp, C.c_int]),

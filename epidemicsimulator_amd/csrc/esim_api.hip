@@ -20,6 +20,7 @@ struct esim_ctx_impl {
     Dev d;
     bool uploaded = false;
     hipStream_t stream = nullptr;
+    bool own_stream = true;
     std::string err;
     // host copies needed for reset
     std::vector<uint16_t> init_state;
@@ -159,7 +160,7 @@ extern "C" void esim_destroy(esim_ctx *ctx)
     free_device(c);
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->kev) (void)hipEventDestroy(ev);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -488,6 +489,29 @@ extern "C" int esim_stream(esim_ctx *ctx, void **stream)
     esim_ctx_impl *c = CTX(ctx);
     if (!c || !stream) return fail(c, ESIM_EINVAL, "esim_stream: null argument");
     *stream = (void *)c->stream;
+    return ESIM_OK;
+}
+
+extern "C" int esim_set_stream(esim_ctx *ctx, void *stream)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c) return ESIM_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)stream;
+    c->own_stream = false;
+    return ESIM_OK;
+}
+
+extern "C" int esim_set_exchange_buffer(esim_ctx *ctx, int which, void *device_ptr)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "no population uploaded");
+    if ((which != 0 && which != 1) || !device_ptr) return fail(c, ESIM_EINVAL, "esim_set_exchange_buffer: bad argument");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (which) c->d.xb = (uint32_t *)device_ptr; else c->d.xa = (uint32_t *)device_ptr;
     return ESIM_OK;
 }
 

@@ -146,8 +146,14 @@ int  esim_step_finish(esim_ctx *ctx, esim_step_result *out /* may be NULL */);
 int  esim_exchange_buffer(esim_ctx *ctx, int which /* 0 = A, 1 = B */, void **device_ptr, size_t *n_u32);
 /* Record log read-back for split-phase runs (records first..first+n-1, 1-based time steps). */
 int  esim_read_records(esim_ctx *ctx, uint32_t first_step, uint32_t n, esim_step_result *out);
-/* The HIP stream all work of this context is enqueued on (hipStream_t as void*). */
+/* The HIP stream all work of this context is enqueued on (hipStream_t as void*).  esim_set_stream
+ * makes the context use a caller-owned stream instead (e.g. the one a collective library orders
+ * its all-reduce against); esim_set_exchange_buffer replaces exchange buffer `which` by caller-owned
+ * device memory of at least the size esim_exchange_buffer reports (e.g. a tensor the collective
+ * library can address). */
 int  esim_stream(esim_ctx *ctx, void **stream);
+int  esim_set_stream(esim_ctx *ctx, void *stream);
+int  esim_set_exchange_buffer(esim_ctx *ctx, int which, void *device_ptr);
 int  esim_synchronize(esim_ctx *ctx);
 
 /* Per-citizen state in reference terms, for visualisation / lookup-table sync / checkpoints

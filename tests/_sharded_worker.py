@@ -1,0 +1,57 @@
+"""One rank of a sharded run (spawned by test_sharded_gpu.py / usable by hand):
+   RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT in the environment; all ranks use cuda:<LOCAL_RANK or 0>.
+Compares this rank's records and its slice of the per-citizen state with the whole-population oracle."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import _oracle
+    from epidemicsimulator_amd import Population, _lib
+    from epidemicsimulator_amd.distributed import ShardedSimulator
+
+    cfg = json.loads(sys.argv[1])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(cfg["backend"], rank=rank, world_size=world)
+    pop = Population.synthetic("york", **cfg["spec"])
+    ep = _lib.default_params(**cfg["params"])
+    sim = ShardedSimulator(pop, rank, world, ep, device_index=int(os.environ.get("LOCAL_RANK", "0")))
+    assert sim.population.n_shared_buildings > 0 or world == 1
+    orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
+    done = 0
+    while done < cfg["steps"]:
+        n = min(cfg["chunk"], cfg["steps"] - done)
+        sim.run(n)
+        sim.synchronize()
+        got = sim.records(done + 1, n)
+        want = orc.run(n)
+        for f in _lib.RECORD_FIELDS:
+            if f == "reserved":
+                continue
+            if not (got[f] == want[f]).all():
+                i = int(np.argmax(got[f] != want[f]))
+                raise AssertionError("rank %d: %s differs at step %d: %d vs oracle %d"
+                                     % (rank, f, done + i + 1, int(got[f][i]), int(want[f][i])))
+        st, ost = sim.download_state(), orc.state()
+        lo, hi = sim.population.citizen_id_base, sim.population.citizen_id_base + sim.population.n_citizens
+        for k in ("status", "timer", "on_bus", "eligible"):
+            assert (st[k] == ost[k][lo:hi]).all(), (rank, k, done)
+        done += n
+    dist.barrier()
+    sim.close()
+    dist.destroy_process_group()
+    print("rank %d ok: %d steps, %d local citizens, %d shared buildings, %d shared rooms"
+          % (rank, cfg["steps"], hi - lo, sim.population.n_shared_buildings, sim.population.n_shared_rooms))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,61 @@
+"""The Output-Area sharded path (split-phase steps + SUM all-reduce of the exchange buffers) against the
+whole-population oracle.  Ranks share the one GPU of the test box and reduce over gloo; on the 8-GPU
+node bench.py runs the same code over nccl (RCCL)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(world, cfg, timeout=420):
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_sharded_worker.py"), json.dumps(cfg)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+    return outs
+
+
+AGGRESSIVE = dict(exposure_chance=0.004, vaccination_rate=40, vaccination_threshold=0.02, lockdown_threshold=0.03,
+                  mask_pt_threshold=0.005, mask_everywhere_threshold=0.01, seed=77, max_steps=700)
+
+
+def test_two_shards_match_oracle():
+    cfg = dict(backend="gloo", spec=dict(n_citizens=12000, n_areas=40, citizens_per_school=2500, n_seeds=16),
+               params=AGGRESSIVE, steps=360, chunk=120)
+    outs = launch(2, cfg)
+    assert all("ok" in o for o in outs)
+
+
+def test_three_uneven_shards_match_oracle():
+    cfg = dict(backend="gloo", spec=dict(n_citizens=9000, n_areas=13, citizens_per_school=3000, n_seeds=16),
+               params=dict(AGGRESSIVE, seed=9), steps=240, chunk=120)
+    outs = launch(3, cfg)
+    assert all("ok" in o for o in outs)
