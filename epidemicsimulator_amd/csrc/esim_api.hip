@@ -24,7 +24,9 @@ struct esim_ctx_impl {
     std::string err;
     // host copies needed for reset
     std::vector<uint16_t> init_state;
+    std::vector<uint32_t> init_log;       // distinct seeds
     size_t cnt_bytes = 0;
+    uint32_t n_routes = 0;
     size_t xa_n = 0, xb_n = 0;
     uint32_t host_t = 1;          // next time step to enqueue
     // device allocations
@@ -32,11 +34,12 @@ struct esim_ctx_impl {
     // timing
     bool phase_timing = false, kernel_timing = false;
     uint32_t kernel_timing_stride = 16;
+    bool timing_this_step = false;
     hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
     double phase_s[3] = { 0, 0, 0 };
-    std::vector<hipEvent_t> kev;       // quadruples: tick start/stop, expose start/stop
+    std::vector<hipEvent_t> kev;       // six per timed step: k_infected, k_expose, k_finish start/stop
     size_t kev_used = 0;
-    uint32_t grid_citizens = 1, grid_bus_small = 1, grid_bus_big = 1;
+    uint32_t grid_citizens = 1, grid_infected = 1, grid_expose = 1;
 };
 
 #define CTX(c) (reinterpret_cast<esim_ctx_impl *>(c))
@@ -132,6 +135,14 @@ extern "C" int esim_create(const esim_params *p, esim_ctx **out)
         return fail(nullptr, ESIM_ERANGE, "esim_create: vaccination_rate above 8192 is not supported");
     if (p->bus_capacity == 0 || p->start_hour == 0 || p->end_hour == 0 || p->start_hour > 24 || p->end_hour > 24)
         return fail(nullptr, ESIM_EINVAL, "esim_create: bad bus_capacity / working hours");
+    {
+        // the schedule is evaluated once for everybody, which needs the four arms of citizen.rs:177-205 to
+        // fall on four different hours
+        const uint32_t h[4] = { (p->start_hour + 23u) % 24u, p->start_hour % 24u, (p->end_hour + 23u) % 24u, p->end_hour % 24u };
+        for (int a = 0; a < 4; ++a) for (int b = a + 1; b < 4; ++b)
+            if (h[a] == h[b]) return fail(nullptr, ESIM_EINVAL, "esim_create: start_hour-1, start_hour, end_hour-1, end_hour must be distinct");
+        if (p->start_hour > 23 || p->end_hour > 23) return fail(nullptr, ESIM_EINVAL, "esim_create: working hours must be in 1..23");
+    }
     if (p->max_steps == 0 || p->max_steps > ESIM_MAX_STEP)
         return fail(nullptr, ESIM_ERANGE, "esim_create: max_steps must be in 1..7600");
     int n_dev = 0;
@@ -224,45 +235,83 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if (fl[i] & FL_USES_PT)
             pairs.emplace_back(((uint64_t)pop->building_area[pop->home_building[i]] << 32) | pop->building_area[pop->work_building[i]], i);
     std::sort(pairs.begin(), pairs.end());
-    std::vector<uint32_t> route_off, riders(pairs.size()), small, big;
+    std::vector<uint32_t> route_off, riders(pairs.size()), route_of(N, NO_ROUTE);
     for (size_t i = 0; i < pairs.size(); ++i) {
         if (i == 0 || pairs[i].first != pairs[i - 1].first) route_off.push_back((uint32_t)i);
         riders[i] = pairs[i].second;
+        route_of[pairs[i].second] = (uint32_t)route_off.size() - 1;
     }
     const uint32_t n_routes = (uint32_t)route_off.size();
     route_off.push_back((uint32_t)pairs.size());
-    for (uint32_t r = 0; r < n_routes; ++r) (route_off[r + 1] - route_off[r] <= 64 ? small : big).push_back(r);
+    bool any_big = false;
+    for (uint32_t r = 0; r < n_routes; ++r) any_big |= route_off[r + 1] - route_off[r] > 64;
+    { std::vector<std::pair<uint64_t, uint32_t>>().swap(pairs); }
+
+    // ---- static member lists (the occupant lists the reference keeps per building:
+    // output_area.rs:172-180, simulator_builder.rs:1076,1100, building.rs:404-431)
+    auto csr = [](uint32_t n_keys, uint32_t n_items, auto key_of, auto use, std::vector<uint32_t> &off, std::vector<uint32_t> &idx) {
+        off.assign((size_t)n_keys + 1, 0);
+        for (uint32_t i = 0; i < n_items; ++i) if (use(i)) off[key_of(i) + 1]++;
+        for (uint32_t k = 0; k < n_keys; ++k) off[k + 1] += off[k];
+        idx.resize(off[n_keys]);
+        std::vector<uint32_t> cur(off.begin(), off.end() - 1);
+        for (uint32_t i = 0; i < n_items; ++i) if (use(i)) idx[cur[key_of(i)]++] = i;
+    };
+    std::vector<uint32_t> res_off, res_idx, wrk_off, wrk_idx, room_off, room_idx;
+    csr(B, N, [&](uint32_t i) { return pop->home_building[i]; }, [&](uint32_t) { return true; }, res_off, res_idx);
+    bool home_sorted = true;
+    for (uint32_t i = 0; i < N && home_sorted; ++i) home_sorted = res_idx[i] == i;
+    csr(B, N, [&](uint32_t i) { return pop->work_building[i]; },
+        [&](uint32_t i) { return (fl[i] & FL_HAS_WORK) && !(fl[i] & FL_WORK_SCHOOL); }, wrk_off, wrk_idx);
+    csr(R, N, [&](uint32_t i) { return room_fixed[i]; }, [&](uint32_t i) { return (fl[i] & FL_WORK_SCHOOL) != 0; }, room_off, room_idx);
 
     // ---- initial state: everyone Susceptible at home (citizen.rs:139-162), seeds Infected(0)
-    c->init_state.assign(N, (uint16_t)TE_SUSCEPTIBLE);
+    c->init_state.assign((size_t)N + 2, (uint16_t)TE_SUSCEPTIBLE);
+    c->init_log.clear();
+    const uint16_t seed_te = (uint16_t)(TE_BIAS - (c->P.exposed_time + 1u));            // Infected(0) before step 1
     for (uint32_t i = 0; i < pop->n_seeds; ++i)
-        c->init_state[pop->seeds[i]] = (uint16_t)(TE_BIAS - (c->P.exposed_time + 1u));   // Infected(0) before step 1
+        if (c->init_state[pop->seeds[i]] != seed_te) { c->init_state[pop->seeds[i]] = seed_te; c->init_log.push_back(pop->seeds[i]); }
 
     free_device(c);
     Dev &d = c->d;
     std::memset(&d, 0, sizeof d);
     d.n = N; d.n_global = n_global; d.id_base = pop->citizen_id_base; d.n_bld = B; d.n_room = R;
+    d.n_pt = (uint32_t)riders.size(); d.n_routes = n_routes; c->n_routes = n_routes;
     int rc;
-    if ((rc = dev_alloc(c, &d.state, N))) return rc;
+    if ((rc = dev_alloc(c, &d.state, (size_t)N + 2))) return rc;
     if ((rc = dev_upload(c, &d.flags, fl.data(), N))) return rc;
     if ((rc = dev_upload(c, &d.home, pop->home_building, N))) return rc;
     if ((rc = dev_upload(c, &d.work, pop->work_building, N))) return rc;
     if ((rc = dev_upload(c, &d.room, room_fixed.data(), N))) return rc;
+    if ((rc = dev_upload(c, &d.res_off, res_off.data(), res_off.size()))) return rc;
+    if (!home_sorted) { if ((rc = dev_upload(c, &d.res_idx, res_idx.data(), res_idx.size()))) return rc; }
+    else d.res_idx = nullptr;
+    if ((rc = dev_upload(c, &d.wrk_off, wrk_off.data(), wrk_off.size()))) return rc;
+    if ((rc = dev_upload(c, &d.wrk_idx, wrk_idx.data(), wrk_idx.size()))) return rc;
+    if ((rc = dev_upload(c, &d.room_off, room_off.data(), room_off.size()))) return rc;
+    if ((rc = dev_upload(c, &d.room_idx, room_idx.data(), room_idx.size()))) return rc;
+    if ((rc = dev_upload(c, &d.room_bld, pop->room_building, R))) return rc;
+    if ((rc = dev_upload(c, &d.bld_type, pop->building_type, B))) return rc;
     uint32_t *cnt = nullptr;
-    if ((rc = dev_alloc(c, &cnt, (size_t)B + R))) return rc;
-    d.cnt_bld = cnt; d.cnt_room = cnt + B;
-    c->cnt_bytes = sizeof(uint32_t) * ((size_t)B + R);
+    if ((rc = dev_alloc(c, &cnt, (size_t)B + R + n_routes))) return rc;
+    d.cnt_bld = cnt; d.cnt_room = cnt + B; d.route_flag = cnt + B + R;
+    c->cnt_bytes = sizeof(uint32_t) * ((size_t)B + R + n_routes);
+    if ((rc = dev_alloc(c, &d.touched_bld, B))) return rc;
+    if ((rc = dev_alloc(c, &d.touched_room, R))) return rc;
+    if ((rc = dev_alloc(c, &d.touched_route, n_routes))) return rc;
+    if ((rc = dev_alloc(c, &d.touched_route_big, n_routes))) return rc;
+    if ((rc = dev_alloc(c, &d.hist, TE_SLOTS))) return rc;
+    if ((rc = dev_alloc(c, &d.log, (size_t)N + 1))) return rc;
+    if ((rc = dev_alloc(c, &d.log_off, TE_SLOTS + 1))) return rc;
     uint64_t lut[512];
     esim_threshold_lut(&c->P, lut);
     if ((rc = dev_upload(c, &d.thr, lut, 512))) return rc;
     if ((rc = dev_alloc(c, &d.ctrl, 1))) return rc;
     if ((rc = dev_alloc(c, &d.records, (size_t)c->P.max_steps + 1))) return rc;
-    d.n_routes_small = (uint32_t)small.size(); d.n_routes_big = (uint32_t)big.size();
-    if ((rc = dev_upload(c, &d.route_small, small.data(), small.size()))) return rc;
-    if ((rc = dev_upload(c, &d.route_big, big.data(), big.size()))) return rc;
     if ((rc = dev_upload(c, &d.route_off, route_off.data(), route_off.size()))) return rc;
     if ((rc = dev_upload(c, &d.route_riders, riders.data(), riders.size()))) return rc;
-    const size_t big_scratch = big.empty() ? 0 : riders.size();
+    if ((rc = dev_upload(c, &d.route_of, route_of.data(), N))) return rc;
+    const size_t big_scratch = any_big ? riders.size() : 0;
     if ((rc = dev_alloc(c, &d.bus_key, big_scratch))) return rc;
     if ((rc = dev_alloc(c, &d.bus_idx, big_scratch))) return rc;
     if ((rc = dev_alloc(c, &d.bus_cnt, big_scratch))) return rc;
@@ -286,8 +335,8 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     HIP_TRY(c, hipMemset(d.xb, 0, sizeof(uint32_t) * c->xb_n));
 
     c->grid_citizens = grid_for(N, TPB, 2048);
-    c->grid_bus_small = grid_for((size_t)d.n_routes_small * 64, TPB, 2048);
-    c->grid_bus_big = grid_for(d.n_routes_big, 1, 1024);
+    c->grid_infected = 256;
+    c->grid_expose = 1024;
     c->uploaded = true;
     return esim_reset(ctx);
 }
@@ -298,14 +347,27 @@ extern "C" int esim_reset(esim_ctx *ctx)
     if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "esim_reset: no population uploaded");
     HIP_TRY(c, hipSetDevice(c->P.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const Dev &d = c->d;
+    const uint32_t n_seeds = (uint32_t)c->init_log.size();
     Ctrl h;
     std::memset(&h, 0, sizeof h);
     h.t = 1;
     h.mask = ESIM_MASK_NONE;
-    HIP_TRY(c, hipMemcpy(c->d.ctrl, &h, sizeof h, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d.state, c->init_state.data(), sizeof(uint16_t) * c->d.n, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemset(c->d.cnt_bld, 0, c->cnt_bytes));
-    HIP_TRY(c, hipMemset(c->d.records, 0, sizeof(esim_step_result) * ((size_t)c->P.max_steps + 1)));
+    h.n_susceptible = d.n - n_seeds;
+    h.log_len = n_seeds;
+    HIP_TRY(c, hipMemcpy(d.ctrl, &h, sizeof h, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(d.state, c->init_state.data(), sizeof(uint16_t) * ((size_t)d.n + 2), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(d.cnt_bld, 0, c->cnt_bytes));
+    HIP_TRY(c, hipMemset(d.records, 0, sizeof(esim_step_result) * ((size_t)c->P.max_steps + 1)));
+    // census histogram and exposure log: the seeds are Infected(0) before step 1, i.e. "exposed" at
+    // step -(exposed_time + 1)
+    const uint32_t seed_te = TE_BIAS - (c->P.exposed_time + 1u);
+    std::vector<uint32_t> hist(TE_SLOTS, 0), off(TE_SLOTS + 1, 0);
+    hist[seed_te] = n_seeds;
+    for (uint32_t k = seed_te + 1; k <= TE_SLOTS; ++k) off[k] = n_seeds;
+    HIP_TRY(c, hipMemcpy(d.hist, hist.data(), sizeof(uint32_t) * TE_SLOTS, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(d.log_off, off.data(), sizeof(uint32_t) * (TE_SLOTS + 1), hipMemcpyHostToDevice));
+    if (n_seeds) HIP_TRY(c, hipMemcpy(d.log, c->init_log.data(), sizeof(uint32_t) * n_seeds, hipMemcpyHostToDevice));
     c->host_t = 1;
     c->phase_s[0] = c->phase_s[1] = c->phase_s[2] = 0;
     c->kev_used = 0;
@@ -318,9 +380,8 @@ int enqueue_begin(esim_ctx_impl *c, bool time_kernel)
 {
     Dev &d = c->d;
     if (c->phase_timing) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-    HIP_TRY(c, hipMemsetAsync(d.cnt_bld, 0, c->cnt_bytes, c->stream));
     if (time_kernel) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 0], c->stream));
-    hipLaunchKernelGGL(k_tick, dim3(c->grid_citizens), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_infected, dim3(c->grid_infected), dim3(TPB), 0, c->stream, d);
     if (time_kernel) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 1], c->stream));
     if (d.n_shards > 1) {
         const uint32_t n = (uint32_t)std::max<size_t>(XA_HEADER, std::max(d.n_shared_bld, d.n_shared_room));
@@ -338,19 +399,19 @@ int enqueue_exposures(esim_ctx_impl *c, bool time_kernel)
         hipLaunchKernelGGL(k_unpack_a, dim3(grid_for(n, TPB, 1u << 20)), dim3(TPB), 0, c->stream, d);
     }
     if (time_kernel) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 2], c->stream));
-    hipLaunchKernelGGL(k_expose, dim3(c->grid_citizens), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_expose, dim3(c->grid_expose), dim3(TPB), 0, c->stream, d);
     if (time_kernel) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 3], c->stream));
-    if (d.n_routes_small) hipLaunchKernelGGL(k_bus_small, dim3(c->grid_bus_small), dim3(TPB), 0, c->stream, d);
-    if (d.n_routes_big) hipLaunchKernelGGL(k_bus_big, dim3(c->grid_bus_big), dim3(TPB), 0, c->stream, d);
     if (d.n_shards > 1) hipLaunchKernelGGL(k_pack_b, dim3(VACC_BATCH / TPB), dim3(TPB), 0, c->stream, d);
     if (c->phase_timing) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     return ESIM_OK;
 }
 
-int enqueue_finish(esim_ctx_impl *c)
+int enqueue_finish(esim_ctx_impl *c, bool time_kernel)
 {
     Dev &d = c->d;
+    if (time_kernel) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 4], c->stream));
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(FIN_TPB), 0, c->stream, d, d.n_shards > 1 ? 1 : 0);
+    if (time_kernel) { HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 5], c->stream)); c->kev_used += 6; }
     if (c->phase_timing) {
         HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
         HIP_TRY(c, hipEventSynchronize(c->ev[3]));
@@ -373,8 +434,8 @@ int check_budget(esim_ctx_impl *c, uint32_t n_steps)
 bool want_kernel_timing(esim_ctx_impl *c)
 {
     if (!c->kernel_timing || (c->host_t % c->kernel_timing_stride) != 0) return false;
-    if (c->kev_used + 4 > c->kev.size()) {
-        for (int i = 0; i < 4; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return false; c->kev.push_back(e); }
+    if (c->kev_used + 6 > c->kev.size()) {
+        for (int i = 0; i < 6; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return false; c->kev.push_back(e); }
     }
     return true;
 }
@@ -395,7 +456,8 @@ extern "C" int esim_step_begin(esim_ctx *ctx)
     int rc = check_budget(c, 1);
     if (rc) return rc;
     HIP_TRY(c, hipSetDevice(c->P.device));
-    return enqueue_begin(c, false);
+    c->timing_this_step = want_kernel_timing(c);
+    return enqueue_begin(c, c->timing_this_step);
 }
 
 extern "C" int esim_step_exposures(esim_ctx *ctx)
@@ -403,7 +465,7 @@ extern "C" int esim_step_exposures(esim_ctx *ctx)
     esim_ctx_impl *c = CTX(ctx);
     if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "no population uploaded");
     HIP_TRY(c, hipSetDevice(c->P.device));
-    return enqueue_exposures(c, false);
+    return enqueue_exposures(c, c->timing_this_step);
 }
 
 extern "C" int esim_step_finish(esim_ctx *ctx, esim_step_result *out)
@@ -411,7 +473,8 @@ extern "C" int esim_step_finish(esim_ctx *ctx, esim_step_result *out)
     esim_ctx_impl *c = CTX(ctx);
     if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "no population uploaded");
     HIP_TRY(c, hipSetDevice(c->P.device));
-    int rc = enqueue_finish(c);
+    int rc = enqueue_finish(c, c->timing_this_step);
+    c->timing_this_step = false;
     if (rc) return rc;
     if (out) {
         HIP_TRY(c, hipMemcpyAsync(out, &c->d.records[c->host_t - 1], sizeof *out, hipMemcpyDeviceToHost, c->stream));
@@ -431,7 +494,7 @@ extern "C" int esim_step(esim_ctx *ctx, esim_step_result *out)
     const bool tk = want_kernel_timing(c);
     if ((rc = enqueue_begin(c, tk))) return rc;
     if ((rc = enqueue_exposures(c, tk))) return rc;
-    if (tk) c->kev_used += 4;
+    c->timing_this_step = tk;
     return esim_step_finish(ctx, out);
 }
 
@@ -449,8 +512,7 @@ extern "C" int esim_run(esim_ctx *ctx, uint32_t n_steps, int stop_when_done, esi
         const bool tk = want_kernel_timing(c);
         if ((rc = enqueue_begin(c, tk))) return rc;
         if ((rc = enqueue_exposures(c, tk))) return rc;
-        if (tk) c->kev_used += 4;
-        if ((rc = enqueue_finish(c))) return rc;
+        if ((rc = enqueue_finish(c, tk))) return rc;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     Ctrl h;
@@ -576,20 +638,21 @@ extern "C" int esim_enable_kernel_timing(esim_ctx *ctx, int enable)
     return ESIM_OK;
 }
 
-extern "C" int esim_kernel_timings(esim_ctx *ctx, double out_ms[2], uint32_t *out_n)
+extern "C" int esim_kernel_timings(esim_ctx *ctx, double out_ms[3], uint32_t *out_n)
 {
     esim_ctx_impl *c = CTX(ctx);
     if (!c || !out_ms) return ESIM_EINVAL;
     HIP_TRY(c, hipSetDevice(c->P.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    double a = 0, b = 0;
-    const size_t n = c->kev_used / 4;
-    for (size_t i = 0; i < n; ++i) {
-        float ms;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * i + 0], c->kev[4 * i + 1])); a += ms;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[4 * i + 2], c->kev[4 * i + 3])); b += ms;
-    }
-    out_ms[0] = n ? a / n : 0.0; out_ms[1] = n ? b / n : 0.0;
+    double acc[3] = { 0, 0, 0 };
+    const size_t n = c->kev_used / 6;
+    for (size_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            float ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[6 * i + 2 * k], c->kev[6 * i + 2 * k + 1]));
+            acc[k] += ms;
+        }
+    for (int k = 0; k < 3; ++k) out_ms[k] = n ? acc[k] / n : 0.0;
     if (out_n) *out_n = (uint32_t)n;
     c->kev_used = 0;
     return ESIM_OK;

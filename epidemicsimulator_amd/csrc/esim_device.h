@@ -3,20 +3,22 @@
 #include <stdint.h>
 
 // ---- per-citizen dynamic state word (uint16, one per citizen, HBM) -------------------------
-// bits 0..12  te : BIAS + (time step at which the citizen became Exposed(0)), or a sentinel.
+// bits 0..12  te : TE_BIAS + (time step at which the citizen became Exposed(0)), or a sentinel.
 //                  DiseaseStatus (disease.rs:36-44) is a pure function of (current step - te):
 //                  the E/I timers of disease.rs:47-71 never have to be written back.
-// bit  13     at_work : current_building_position == workplace_code (citizen.rs:127,187,199)
-// bit  14     on_bus  : on_public_transport.is_some() (citizen.rs:134)
-// bit  15     eligible: member of citizens_eligible_for_vaccine (simulator.rs:97)
-#define ST_TE_MASK   0x1FFFu
-#define ST_AT_WORK   0x2000u
-#define ST_ON_BUS    0x4000u
-#define ST_ELIGIBLE  0x8000u
+// bit  13     bus_exposed : the exposure happened on public transport while a vaccination
+//                  programme was running (the citizen left citizens_eligible_for_vaccine,
+//                  simulator.rs:447-449)
+// Where a citizen stands (home / work / on a bus) is NOT per-citizen state: every citizen has
+// the same working hours (citizen.rs:154-155), so current_building_position and
+// on_public_transport are global functions of the clock and the lockdown history (Ctrl).
+#define ST_TE_MASK     0x1FFFu
+#define ST_BUS_EXPOSED 0x2000u
 #define TE_SUSCEPTIBLE 0x1FFFu
 #define TE_VACCINATED  0x1FFEu
 #define TE_RECOVERED   0x1FFDu
 #define TE_BIAS        512u          // >= exposed_time + infected_time + 2
+#define TE_SLOTS       8192u
 #define ESIM_MAX_STEP  7600u         // TE_BIAS + step must stay below TE_RECOVERED
 
 // ---- per-citizen static flags (uint8) ------------------------------------------------------
@@ -29,6 +31,7 @@
 #define VACC_BATCH 4096u             // vaccination candidates examined per batch
 #define VACC_TABLE 16384u            // LDS hash-set slots (>= max rate + VACC_BATCH, power of two)
 #define VACC_MAX_RATE 8192u
+#define NO_ROUTE 0xFFFFFFFFu
 
 struct Ctrl {
     uint32_t t;                 // time step being processed (1-based; statistics.rs:167)
@@ -36,38 +39,55 @@ struct Ctrl {
     uint32_t mask;              // mask_status in force during this step's exposures
     uint32_t vacc_active;       // InterventionStatus.vaccination.is_some()
     uint32_t have_elig;         // citizens_eligible_for_vaccine.is_some()
-    uint32_t elig_count;        // |citizens_eligible_for_vaccine| (this shard until exchanged)
+    uint32_t trigger_step;      // step whose end created the eligible set (simulator.rs:481-513)
+    uint32_t elig_count;        // |citizens_eligible_for_vaccine| (this shard)
     uint32_t finished;          // disease_exists() was false and the run asked to stop
     uint32_t stop_when_done;
-    uint32_t bus_dir;           // direction of everyone currently on a bus: 1 home->work, 2 work->home
+    uint32_t at_work;           // global position: 1 after the "starts work" arm (citizen.rs:186-189)
+    uint32_t bus_dir;           // everyone using public transport: 0 off, 1 home->work, 2 work->home
     uint32_t steps_done;
     uint32_t error;             // sticky ESIM_E* (negated) raised on the device
-    // accumulators of the step in flight (zeroed by k_finish)
-    uint32_t counts[5];         // S,E,I,R,V census after Citizen::execute_time_step (simulator.rs:178)
-    uint32_t n_riders;
+    // census bookkeeping (this shard): Susceptible and Vaccinated citizens; the rest sits in hist[]
+    uint32_t n_susceptible, n_vaccinated, n_recovered_sentinel;
+    uint32_t log_len;           // entries in the exposure log
+    // per-step work lists (zeroed by k_finish)
+    uint32_t n_touched_bld, n_touched_room, n_touched_route, n_touched_route_big;
     uint32_t exp_bld, exp_bus;
-    uint32_t pad[12];
+    uint32_t counts[5];         // census of the step in flight (global when sharded, after unpack)
+    uint32_t n_riders;
+    uint32_t pad[3];
 };
 
 struct Dev {
     uint32_t n;                 // citizens on this shard
     uint32_t n_global;          // citizens over all shards
     uint32_t id_base;           // global index of local citizen 0
-    uint32_t n_bld, n_room;
+    uint32_t n_bld, n_room, n_pt;
     uint16_t *state;
     const uint8_t  *flags;
     const uint32_t *home, *work, *room;
+    // static membership lists (the reference's occupant lists: output_area.rs:172-180,
+    // simulator_builder.rs:1076,1100, building.rs:404-431)
+    const uint32_t *res_off, *res_idx;      // residents per building; res_idx == nullptr: citizens are home-sorted
+    const uint32_t *wrk_off, *wrk_idx;      // workers per non-school building
+    const uint32_t *room_off, *room_idx;    // participants per school room
+    const uint32_t *room_bld;               // [n_room] school of each room
+    const uint8_t  *bld_type;
     uint32_t *cnt_bld;          // [n_bld] infected citizens standing in each building this step
     uint32_t *cnt_room;         // [n_room] ... in each school room
+    uint32_t *touched_bld, *touched_room, *touched_route, *touched_route_big;
+    uint32_t *route_flag;       // [n_routes]
+    uint32_t *hist;             // [TE_SLOTS] citizens per exposure time (census without a pass over citizens)
+    uint32_t *log;              // exposure log: citizen ids in order of exposure step
+    uint32_t *log_off;          // [TE_SLOTS + 1] first log entry whose te >= k
     const uint64_t *thr;        // [2][256] ceil(q * 2^53)
     Ctrl *ctrl;
     struct esim_step_result *records;   // [max_steps + 1]
     // public transport: static route lists (riders of a route share (home area, work area))
-    uint32_t n_routes_small, n_routes_big;
-    const uint32_t *route_small;        // route ids with <= 64 riders
-    const uint32_t *route_big;
+    uint32_t n_routes;
     const uint32_t *route_off;          // [n_routes + 1]
     const uint32_t *route_riders;       // local citizen ids, ascending inside a route
+    const uint32_t *route_of;           // [n] route of a citizen using public transport, else NO_ROUTE
     uint32_t *bus_key; uint32_t *bus_idx; uint32_t *bus_cnt; uint8_t *bus_flag;   // scratch for big routes
     // parameters
     uint32_t exposed_time, infected_time, vaccination_rate, bus_capacity, start_hour, end_hour;

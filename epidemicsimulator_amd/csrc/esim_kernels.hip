@@ -1,10 +1,18 @@
 // esim_kernels.hip -- gfx950 kernels of the per-timestep Citizen update loop.
 //
 // One time step (reference: Simulator::step, sim/src/simulator.rs:131-152) is, on the device:
-//   k_tick     generate_exposures  (simulator.rs:155-260): schedule + census + infected-per-building
-//   k_expose   apply_exposures, buildings (simulator.rs:268-358)
-//   k_bus_*    apply_exposures, public transport (simulator.rs:360-401)
-//   k_finish   apply_interventions (simulator.rs:455-556) + the StatisticEntry of the step
+//   k_infected  generate_exposures (simulator.rs:155-260): every currently Infected citizen that is
+//               not on a bus marks the building (and school room) it stands in; riders mark their route
+//   k_expose    apply_exposures (simulator.rs:262-405): for every marked building / room / route,
+//               walk its registered members exactly as Building::find_exposures does and draw
+//   k_finish    apply_interventions (simulator.rs:455-556), the census and the StatisticEntry
+//
+// Work-efficient by construction:
+//  * DiseaseStatus is a function of (step - exposure step), so the census of simulator.rs:178 is a
+//    sliding-window sum over a histogram of exposure steps, not a pass over citizens;
+//  * citizens are appended to an exposure log when they become Exposed(0), so "everyone Infected in
+//    step t" is one contiguous slice of that log;
+//  * where citizens stand is global (same working hours for everybody, citizen.rs:154-155).
 // All draws are Philox4x32-10 keyed (global citizen, step, slot); probabilities are integer
 // thresholds ceil(q*2^53) from a host-built LUT, so every comparison is exact integer work.
 #include <hip/hip_runtime.h>
@@ -25,67 +33,87 @@ __device__ __forceinline__ uint32_t status_of(uint32_t te, uint32_t t, uint32_t 
     return ESIM_RECOVERED;
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+// Citizen::execute_time_step's schedule (citizen.rs:176-206) for the whole population at once.
+// The four hours are distinct (checked in esim_create), so every citizen takes the same arm
+// up to the `uses_public_transport` guard, which only decides who is on the bus.
+__device__ __forceinline__ void schedule(const Dev &d, const Ctrl *ctrl, uint32_t t, uint32_t &at_work, uint32_t &bus_dir)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    at_work = ctrl->at_work; bus_dir = ctrl->bus_dir;
+    if (ctrl->lockdown) return;                                   // citizen.rs:176 (Q8)
+    const uint32_t h = t % 24u;
+    if (h == d.start_hour - 1u) bus_dir = 1u;                     // :179-184 (users of public transport)
+    else if (h == d.start_hour) { at_work = 1u; bus_dir = 0u; }   // :186-189
+    else if (h == d.end_hour - 1u) bus_dir = 2u;                  // :191-196
+    else if (h == d.end_hour) { at_work = 0u; bus_dir = 0u; }     // :198-201
+    else bus_dir = 0u;                                            // :202-204
 }
 
-// ------------------------------------------------------------------------------------ k_tick
-// Citizen::execute_time_step (citizen.rs:168-216) for every citizen, the census of
-// simulator.rs:178, the rider test of :181-186 and the infected-building push of :187-198.
-__global__ __launch_bounds__(TPB) void k_tick(Dev d)
+// Census of simulator.rs:178 from the exposure-time histogram; called by a whole block.
+// out[0..4] = S,E,I,R,V of this shard after the tick of step t (before this step's exposures).
+__device__ void census_block(const Dev &d, const Ctrl *ctrl, uint32_t t, uint32_t *out /* shared, >= 5 */)
+{
+    if (threadIdx.x < 5) out[threadIdx.x] = 0;
+    __syncthreads();
+    const int hi_e = (int)(t + TE_BIAS);                          // d = 0
+    const int lo_e = hi_e - (int)d.exposed_time;                  // d = exposed_time
+    const int hi_i = lo_e - 1;                                    // d = exposed_time + 1
+    const int lo_i = hi_i - (int)d.infected_time;
+    uint32_t e = 0, i = 0;
+    for (int k = lo_i + (int)threadIdx.x; k <= hi_e; k += (int)blockDim.x) {
+        if (k < 0) continue;
+        const uint32_t v = d.hist[k];
+        if (k >= lo_e) e += v; else i += v;
+    }
+    if (e) atomicAdd(&out[1], e);
+    if (i) atomicAdd(&out[2], i);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = ctrl->n_susceptible; out[4] = ctrl->n_vaccinated;
+        out[3] = d.n - out[0] - out[4] - out[1] - out[2];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void append(uint32_t *list, uint32_t *len, uint32_t v)
+{
+    list[atomicAdd(len, 1u)] = v;
+}
+
+// ---------------------------------------------------------------------------------- k_infected
+// The Infected citizens of step t are the log slice with exposure step in
+// [t - exposed_time - 1 - infected_time, t - exposed_time - 1].  simulator.rs:181-198: a rider
+// joins its route's session, anybody else marks current_building_position.
+__global__ __launch_bounds__(TPB) void k_infected(Dev d)
 {
     Ctrl *ctrl = d.ctrl;
     if (ctrl->finished) return;
     const uint32_t t = ctrl->t;
-    const bool lock = ctrl->lockdown != 0;
-    const uint32_t h = t % 24u;
-    uint32_t cS = 0, cE = 0, cI = 0, cR = 0, cV = 0, cB = 0;
-    for (uint32_t c = blockIdx.x * TPB + threadIdx.x; c < d.n; c += gridDim.x * TPB) {
-        const uint32_t st = d.state[c];
+    uint32_t at_work, bus_dir;
+    schedule(d, ctrl, t, at_work, bus_dir);
+    const int hi = (int)(t + TE_BIAS) - (int)d.exposed_time - 1;
+    const int lo = hi - (int)d.infected_time;
+    if (hi < 0) return;
+    const uint32_t i0 = d.log_off[lo < 0 ? 0 : lo], i1 = d.log_off[hi + 1];
+    for (uint32_t i = i0 + blockIdx.x * TPB + threadIdx.x; i < i1; i += gridDim.x * TPB) {
+        const uint32_t c = d.log[i];
+        if (status_of(d.state[c] & ST_TE_MASK, t, d.exposed_time, d.infected_time) != ESIM_INFECTED) continue;  // vaccinated since (Q10)
         const uint32_t fl = d.flags[c];
-        uint32_t ns = st;
-        if (!lock) {                                                      // citizen.rs:176
-            const bool pt = fl & FL_USES_PT;
-            if (h == d.start_hour - 1u && pt) ns |= ST_ON_BUS;            // :179-184
-            else if (h == d.start_hour) ns = (ns | ST_AT_WORK) & ~ST_ON_BUS;   // :186-189
-            else if (h == d.end_hour - 1u && pt) ns |= ST_ON_BUS;         // :191-196
-            else if (h == d.end_hour) ns &= ~(ST_AT_WORK | ST_ON_BUS);    // :198-201
-            else ns &= ~ST_ON_BUS;                                        // :202-204
+        if (bus_dir && (fl & FL_USES_PT)) {                                  // simulator.rs:181-186
+            const uint32_t r = d.route_of[c];
+            if (atomicExch(&d.route_flag[r], 1u) == 0u) {
+                if (d.route_off[r + 1] - d.route_off[r] <= 64u) append(d.touched_route, &ctrl->n_touched_route, r);
+                else append(d.touched_route_big, &ctrl->n_touched_route_big, r);
+            }
+        } else {                                                             // :187-198
+            const bool atw = at_work && (fl & FL_HAS_WORK);
+            const uint32_t b = atw ? d.work[c] : d.home[c];
+            if (atomicAdd(&d.cnt_bld[b], 1u) == 0u) append(d.touched_bld, &ctrl->n_touched_bld, b);
+            if (atw && (fl & FL_WORK_SCHOOL)) {
+                const uint32_t r = d.room[c];
+                if (atomicAdd(&d.cnt_room[r], 1u) == 0u) append(d.touched_room, &ctrl->n_touched_room, r);
+            }
         }
-        const uint32_t cls = status_of(ns & ST_TE_MASK, t, d.exposed_time, d.infected_time);
-        cS += cls == ESIM_SUSCEPTIBLE; cE += cls == ESIM_EXPOSED; cI += cls == ESIM_INFECTED;
-        cR += cls == ESIM_RECOVERED;   cV += cls == ESIM_VACCINATED;
-        if (ns & ST_ON_BUS) cB++;                                         // simulator.rs:181-186
-        else if (cls == ESIM_INFECTED) {                                  // :187-198
-            const bool at_work = (ns & ST_AT_WORK) && (fl & FL_HAS_WORK);
-            const uint32_t b = at_work ? d.work[c] : d.home[c];
-            atomicAdd(&d.cnt_bld[b], 1u);
-            if (at_work && (fl & FL_WORK_SCHOOL)) atomicAdd(&d.cnt_room[d.room[c]], 1u);
-        }
-        if (ns != st) d.state[c] = (uint16_t)ns;
     }
-    __shared__ uint32_t red[6][TPB / 64];
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    cS = wave_sum(cS); cE = wave_sum(cE); cI = wave_sum(cI); cR = wave_sum(cR); cV = wave_sum(cV); cB = wave_sum(cB);
-    if (lane == 0) { red[0][wv] = cS; red[1][wv] = cE; red[2][wv] = cI; red[3][wv] = cR; red[4][wv] = cV; red[5][wv] = cB; }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        uint32_t s = 0;
-        for (uint32_t w = 0; w < TPB / 64; ++w) s += red[threadIdx.x][w];
-        if (s) atomicAdd(threadIdx.x < 5 ? &ctrl->counts[threadIdx.x] : &ctrl->n_riders, s);
-    }
-}
-
-// Did the vaccination programme start in this step?  (interventions.rs:132-141; the infected
-// fraction only depends on the census, because exposures move S->E and leave I alone.)
-__device__ __forceinline__ bool trigger_now(const Dev &d, const Ctrl *ctrl)
-{
-    const uint32_t total = ctrl->counts[0] + ctrl->counts[1] + ctrl->counts[2] + ctrl->counts[3] + ctrl->counts[4];
-    const double x = (double)ctrl->counts[2] / (double)total;          // statistics.rs:252-254
-    return !ctrl->vacc_active && d.thr_vacc < x;
 }
 
 // Threshold for Citizen::expose (citizen.rs:221-248): row 1 of the LUT is p - p*mask_effectiveness,
@@ -96,26 +124,45 @@ __device__ __forceinline__ uint64_t threshold(const Dev &d, uint32_t fl, uint32_
     return d.thr[row * 256u + (n & 255u)];                              // `as u8`, citizen.rs:239
 }
 
-// All building draws of one susceptible citizen in step t (simulator.rs:308-350 seen from the
-// candidate's side): the home list (building.rs:202), then the work list (building.rs:278) or
-// the school-room multiset (building.rs:494-522).  Pure function of the infected counts.
-__device__ __forceinline__ bool building_draws(const Dev &d, uint32_t c, uint32_t st, uint32_t fl,
-                                               uint32_t t, uint32_t mask)
+// Susceptible -> Exposed(0) (citizen.rs:244) exactly once per citizen even when several member
+// lists reach the same citizen concurrently: CAS on the 32-bit word holding the 16-bit state.
+__device__ __forceinline__ bool expose_once(const Dev &d, Ctrl *ctrl, uint32_t m, uint32_t new_state)
+{
+    uint32_t *w = reinterpret_cast<uint32_t *>(d.state + (m & ~1u));
+    const uint32_t sh = (m & 1u) * 16u;
+    uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (((old >> sh) & ST_TE_MASK) != TE_SUSCEPTIBLE) return false;
+        const uint32_t nw = (old & ~(0xFFFFu << sh)) | (new_state << sh);
+        const uint32_t prev = atomicCAS(w, old, nw);
+        if (prev == old) break;
+        old = prev;
+    }
+    append(d.log, &ctrl->log_len, m);
+    return true;
+}
+
+// All building draws of one susceptible citizen in step t seen from the candidate's side
+// (simulator.rs:308-350): the home list (building.rs:202), then the work list (building.rs:278) or
+// the school-room multiset (building.rs:494-522).  Pure function of the infected counts; the bus
+// phase uses it to know whether the building phase exposes a rider (simulator.rs:436 only reaches
+// riders that are still Susceptible after the buildings).
+__device__ __forceinline__ bool building_draws(const Dev &d, uint32_t c, uint32_t fl, uint32_t t, uint32_t mask,
+                                               uint32_t at_work)
 {
     const uint32_t g = d.id_base + c;
-    const bool at_work = st & ST_AT_WORK;
+    const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
+    const bool atw = at_work && (fl & FL_HAS_WORK);
     const bool same = fl & FL_SAME_AREA;
     // "If the Citizen is not currently in the Area, they haven't been exposed!" simulator.rs:324
-    if (!at_work || same) {
+    if (!atw || same) {
         const uint32_t n = d.cnt_bld[d.home[c]];
-        if (n && esim_u53(((uint64_t)d.seed_hi << 32) | d.seed_lo, g, t, ESIM_SLOT_HOME) < threshold(d, fl, mask, n))
-            return true;
+        if (n && esim_u53(seed, g, t, ESIM_SLOT_HOME) < threshold(d, fl, mask, n)) return true;
     }
     if ((fl & FL_HAS_WORK) && (at_work || same)) {
         const uint32_t n = d.cnt_bld[d.work[c]];
         if (n) {
             const uint64_t thr = threshold(d, fl, mask, n);
-            const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
             if (fl & FL_WORK_SCHOOL) {
                 const uint32_t k = d.cnt_room[d.room[c]];               // one copy of the room per infected
                 for (uint32_t j = 0; j < k; ++j)
@@ -126,151 +173,152 @@ __device__ __forceinline__ bool building_draws(const Dev &d, uint32_t c, uint32_
     return false;
 }
 
+// One candidate of one member list (simulator.rs:308-350 for one citizen_id of find_exposures).
+// kind 0: resident (home list), 1: worker (work list), 2: room participant (k draws).
+__device__ __forceinline__ void member_draw(const Dev &d, Ctrl *ctrl, uint32_t m, uint32_t kind, uint32_t n, uint32_t k,
+                                            uint32_t t, uint32_t mask, uint32_t at_work, uint32_t &n_exp)
+{
+    const uint32_t st = d.state[m];
+    if ((st & ST_TE_MASK) != TE_SUSCEPTIBLE) return;                     // is_susceptible(), simulator.rs:337
+    const uint32_t fl = d.flags[m];
+    const bool same = fl & FL_SAME_AREA;
+    // area of current_building_position == area of this building?  simulator.rs:324
+    if (kind == 0u) { if (at_work && (fl & FL_HAS_WORK) && !same) return; }
+    else if (!at_work && !same) return;
+    const uint64_t thr = threshold(d, fl, mask, n);
+    const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
+    const uint32_t g = d.id_base + m;
+    bool hit = false;
+    if (kind == 2u) { for (uint32_t j = 0; j < k && !hit; ++j) hit = esim_u53(seed, g, t, ESIM_SLOT_ROOM0 + j) < thr; }
+    else hit = esim_u53(seed, g, t, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK) < thr;
+    if (hit && expose_once(d, ctrl, m, t + TE_BIAS)) n_exp++;            // Exposed(0), citizen.rs:244
+}
+
+// A rider that the building phase leaves Susceptible draws once with the number of infected
+// riders on the same bus (expose_citizens, simulator.rs:407-453).
+__device__ __forceinline__ void bus_draw(const Dev &d, Ctrl *ctrl, uint32_t c, uint32_t k, uint32_t t, uint32_t mask,
+                                         uint32_t at_work)
+{
+    const uint32_t fl = d.flags[c];
+    if (building_draws(d, c, fl, t, mask, at_work)) return;              // the buildings got there first
+    const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
+    if (esim_u53(seed, d.id_base + c, t, ESIM_SLOT_BUS) < threshold(d, fl, mask, k)) {
+        if (expose_once(d, ctrl, c, (t + TE_BIAS) | ST_BUS_EXPOSED)) {
+            atomicAdd(&ctrl->exp_bus, 1u);
+            if (ctrl->have_elig) atomicSub(&ctrl->elig_count, 1u);       // simulator.rs:447-449 (a Susceptible is eligible)
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- k_expose
+// apply_exposures.  Work items: marked buildings (residents + workers), marked school rooms,
+// marked routes of <= 64 riders -- one wavefront each, lanes over the members; then marked
+// routes of > 64 riders, one workgroup each.
 __global__ __launch_bounds__(TPB) void k_expose(Dev d)
 {
     Ctrl *ctrl = d.ctrl;
     if (ctrl->finished) return;
     const uint32_t t = ctrl->t, mask = ctrl->mask;
-    const bool trig = trigger_now(d, ctrl);
-    uint32_t n_exp = 0, n_elig = 0;
-    for (uint32_t c = blockIdx.x * TPB + threadIdx.x; c < d.n; c += gridDim.x * TPB) {
-        const uint32_t st = d.state[c];
-        if ((st & ST_TE_MASK) != TE_SUSCEPTIBLE) continue;               // is_susceptible(), simulator.rs:337
-        const uint32_t fl = d.flags[c];
-        if (building_draws(d, c, st, fl, t, mask)) {
-            d.state[c] = (uint16_t)((st & ~ST_TE_MASK) | (t + TE_BIAS));  // Exposed(0), citizen.rs:244
-            n_exp++;
-        } else if (trig) {
-            // eligible := everyone still Susceptible at the end of the trigger step (simulator.rs:487-513);
-            // bus exposures of this step take the bit away again in k_bus_*.
-            d.state[c] = (uint16_t)(st | ST_ELIGIBLE);
-            n_elig++;
-        }
-    }
-    __shared__ uint32_t red[2][TPB / 64];
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    n_exp = wave_sum(n_exp); n_elig = wave_sum(n_elig);
-    if (lane == 0) { red[0][wv] = n_exp; red[1][wv] = n_elig; }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-        uint32_t s = 0;
-        for (uint32_t w = 0; w < TPB / 64; ++w) s += red[threadIdx.x][w];
-        if (s) atomicAdd(threadIdx.x == 0 ? &ctrl->exp_bld : &ctrl->elig_count, s);
-    }
-}
-
-// ------------------------------------------------------------------------------------- buses
-// A rider that is still Susceptible after the building phase draws once with the number of
-// infected riders on the same bus (expose_citizens, simulator.rs:407-453).
-__device__ __forceinline__ void bus_draw(const Dev &d, Ctrl *ctrl, uint32_t c, uint32_t st, uint32_t k,
-                                         uint32_t t, uint32_t mask)
-{
-    const uint32_t fl = d.flags[c];
-    const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
-    if (esim_u53(seed, d.id_base + c, t, ESIM_SLOT_BUS) < threshold(d, fl, mask, k)) {
-        d.state[c] = (uint16_t)((st & ~(ST_TE_MASK | ST_ELIGIBLE)) | (t + TE_BIAS));
-        atomicAdd(&ctrl->exp_bus, 1u);
-        if (st & ST_ELIGIBLE) atomicSub(&ctrl->elig_count, 1u);           // simulator.rs:447-449
-    }
-}
-
-// One wavefront per route with <= 64 riders: rank by (Philox key, id) with shuffles, buses are
-// consecutive runs of bus_capacity ranks (replaces shuffle + pop, simulator.rs:362-388).
-__global__ __launch_bounds__(TPB) void k_bus_small(Dev d)
-{
-    Ctrl *ctrl = d.ctrl;
-    if (ctrl->finished || ctrl->n_riders == 0) return;
-    const uint32_t t = ctrl->t, mask = ctrl->mask;
+    uint32_t at_work, bus_dir;
+    schedule(d, ctrl, t, at_work, bus_dir);
+    const uint32_t nb = ctrl->n_touched_bld, nr = ctrl->n_touched_room, nrt = ctrl->n_touched_route;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
-    for (uint32_t ri = wave; ri < d.n_routes_small; ri += n_waves) {
-        const uint32_t r = d.route_small[ri];
-        const uint32_t off = d.route_off[r], s = d.route_off[r + 1] - off;
-        uint32_t c = 0, st = 0;
-        bool active = false, inf = false;
-        if (lane < s) {
-            c = d.route_riders[off + lane];
-            st = d.state[c];
-            active = st & ST_ON_BUS;
-            inf = active && status_of(st & ST_TE_MASK, t, d.exposed_time, d.infected_time) == ESIM_INFECTED;
+    uint32_t n_exp = 0;
+    for (uint32_t it = wave; it < nb + nr + nrt; it += n_waves) {
+        if (it < nb) {
+            const uint32_t b = d.touched_bld[it];
+            if (d.bld_type[b] == ESIM_SCHOOL) continue;                  // School::find_exposures works per room
+            const uint32_t n = d.cnt_bld[b];                             // exposure_count, simulator.rs:307
+            // Household / Workplace::find_exposures: every registered occupant (building.rs:202-204,278-280)
+            for (uint32_t k = d.res_off[b] + lane; k < d.res_off[b + 1]; k += 64u)
+                member_draw(d, ctrl, d.res_idx ? d.res_idx[k] : k, 0u, n, 0u, t, mask, at_work, n_exp);
+            for (uint32_t k = d.wrk_off[b] + lane; k < d.wrk_off[b + 1]; k += 64u)
+                member_draw(d, ctrl, d.wrk_idx[k], 1u, n, 0u, t, mask, at_work, n_exp);
+        } else if (it < nb + nr) {
+            const uint32_t r = d.touched_room[it - nb];
+            const uint32_t k = d.cnt_room[r];                            // one copy of the room per infected in it
+            const uint32_t n = d.cnt_bld[d.room_bld[r]];                 // infected in the whole school
+            for (uint32_t q = d.room_off[r] + lane; q < d.room_off[r + 1]; q += 64u)
+                member_draw(d, ctrl, d.room_idx[q], 2u, n, k, t, mask, at_work, n_exp);
+        } else {
+            // route of <= 64 riders: rank by (Philox key, id) with shuffles; buses are consecutive runs of
+            // bus_capacity ranks (replaces shuffle + pop, simulator.rs:362-388)
+            const uint32_t r = d.touched_route[it - nb - nr];
+            const uint32_t off = d.route_off[r], s = d.route_off[r + 1] - off;
+            uint32_t c = 0, st = 0, key = 0;
+            bool inf = false;
+            if (lane < s) {
+                c = d.route_riders[off + lane];
+                st = d.state[c];
+                inf = status_of(st & ST_TE_MASK, t, d.exposed_time, d.infected_time) == ESIM_INFECTED;
+                key = philox4x32_10(d.id_base + c, t, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
+            }
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < s; ++j) {
+                const uint32_t kj = __shfl(key, j, 64);
+                rank += kj < key || (kj == key && j < lane);             // ids ascend with the lane
+            }
+            const uint32_t bus = rank / d.bus_capacity;
+            uint32_t k = 0;
+            for (uint32_t j = 0; j < s; ++j) {
+                const uint32_t bj = __shfl(bus, j, 64);
+                const bool ij = __shfl((int)inf, j, 64);
+                k += ij && bj == bus;
+            }
+            if (lane < s && k && (st & ST_TE_MASK) == TE_SUSCEPTIBLE) bus_draw(d, ctrl, c, k, t, mask, at_work);
         }
-        if (!__any(inf)) continue;                                        // no bus of this route has exposure_count > 0
-        const uint32_t key = active ? philox4x32_10(d.id_base + c, t, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0 : 0u;
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < s; ++j) {
-            const uint32_t kj = __shfl(key, j, 64);
-            const bool aj = __shfl((int)active, j, 64);
-            rank += aj && (kj < key || (kj == key && j < lane));          // ids ascend with the lane
-        }
-        const uint32_t bus = rank / d.bus_capacity;
-        uint32_t k = 0;
-        for (uint32_t j = 0; j < s; ++j) {
-            const uint32_t bj = __shfl(bus, j, 64);
-            const bool ij = __shfl((int)inf, j, 64);
-            k += ij && bj == bus;
-        }
-        if (active && k && (st & ST_TE_MASK) == TE_SUSCEPTIBLE) bus_draw(d, ctrl, c, st, k, t, mask);
     }
-}
-
-// One workgroup per route with > 64 riders (rare: a very large Output Area).  Same ordering rule,
-// rank by counting through global scratch.
-__global__ __launch_bounds__(TPB) void k_bus_big(Dev d)
-{
-    Ctrl *ctrl = d.ctrl;
-    if (ctrl->finished || ctrl->n_riders == 0) return;
-    const uint32_t t = ctrl->t, mask = ctrl->mask;
-    for (uint32_t ri = blockIdx.x; ri < d.n_routes_big; ri += gridDim.x) {
-        const uint32_t r = d.route_big[ri];
+    // routes of > 64 riders (rare: a very large Output Area): rank by counting through global scratch
+    const uint32_t nbig = ctrl->n_touched_route_big;
+    for (uint32_t ri = blockIdx.x; ri < nbig; ri += gridDim.x) {
+        const uint32_t r = d.touched_route_big[ri];
         const uint32_t off = d.route_off[r], s = d.route_off[r + 1] - off;
-        int any_inf = 0;
         for (uint32_t i = threadIdx.x; i < s; i += TPB) {
             const uint32_t c = d.route_riders[off + i];
-            const uint32_t st = d.state[c];
-            const bool active = st & ST_ON_BUS;
-            const bool inf = active && status_of(st & ST_TE_MASK, t, d.exposed_time, d.infected_time) == ESIM_INFECTED;
-            d.bus_key[off + i] = active ? philox4x32_10(d.id_base + c, t, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0 : 0u;
-            d.bus_flag[off + i] = (uint8_t)((active ? 1u : 0u) | (inf ? 2u : 0u));
+            const bool inf = status_of(d.state[c] & ST_TE_MASK, t, d.exposed_time, d.infected_time) == ESIM_INFECTED;
+            d.bus_key[off + i] = philox4x32_10(d.id_base + c, t, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
+            d.bus_flag[off + i] = inf ? 1u : 0u;
             d.bus_cnt[off + i] = 0u;
-            any_inf |= inf;
         }
-        any_inf = __syncthreads_or(any_inf);
-        if (!any_inf) continue;
+        __syncthreads();
         for (uint32_t i = threadIdx.x; i < s; i += TPB) {
-            const uint32_t fi = d.bus_flag[off + i];
-            if (!(fi & 1u)) continue;
             const uint32_t key = d.bus_key[off + i];
             uint32_t rank = 0;
             for (uint32_t j = 0; j < s; ++j) {
                 const uint32_t kj = d.bus_key[off + j];
-                rank += (d.bus_flag[off + j] & 1u) && (kj < key || (kj == key && j < i));
+                rank += kj < key || (kj == key && j < i);
             }
             const uint32_t bus = rank / d.bus_capacity;
             d.bus_idx[off + i] = bus;
-            if (fi & 2u) atomicAdd(&d.bus_cnt[off + bus], 1u);
+            if (d.bus_flag[off + i]) atomicAdd(&d.bus_cnt[off + bus], 1u);
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < s; i += TPB) {
-            if (!(d.bus_flag[off + i] & 1u)) continue;
             const uint32_t c = d.route_riders[off + i];
-            const uint32_t st = d.state[c];
             const uint32_t k = __hip_atomic_load(&d.bus_cnt[off + d.bus_idx[off + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (k && (st & ST_TE_MASK) == TE_SUSCEPTIBLE) bus_draw(d, ctrl, c, st, k, t, mask);
+            if (k && (d.state[c] & ST_TE_MASK) == TE_SUSCEPTIBLE) bus_draw(d, ctrl, c, k, t, mask, at_work);
         }
         __syncthreads();
     }
+    if (n_exp) atomicAdd(&ctrl->exp_bld, n_exp);
 }
 
 // ---------------------------------------------------------------------------------- exchange
 // Sharded runs: pack the census and the infected counts of shared buildings/rooms, let the caller
-// SUM-all-reduce, and scatter the totals back.
+// SUM-all-reduce, and scatter the totals back (marking what remote infected citizens touched).
 __global__ __launch_bounds__(TPB) void k_pack_a(Dev d)
 {
+    __shared__ uint32_t cen[5];
     const Ctrl *ctrl = d.ctrl;
     const uint32_t i = blockIdx.x * TPB + threadIdx.x;
     const uint32_t nb = d.n_shared_bld, nr = d.n_shared_room;
-    if (i < XA_HEADER) d.xa[i] = i < 5 ? ctrl->counts[i] : (i == 5 ? ctrl->n_riders : 0u);
+    if (blockIdx.x == 0) {
+        census_block(d, ctrl, ctrl->t, cen);
+        uint32_t at_work, bus_dir;
+        schedule(d, ctrl, ctrl->t, at_work, bus_dir);
+        if (threadIdx.x < XA_HEADER) d.xa[threadIdx.x] = threadIdx.x < 5 ? cen[threadIdx.x] : (threadIdx.x == 5 && bus_dir ? d.n_pt : 0u);
+    }
     if (i < nb) { const int32_t l = d.shared_bld[i]; d.xa[XA_HEADER + i] = l >= 0 ? d.cnt_bld[l] : 0u; }
     if (i < nr) { const int32_t l = d.shared_room[i]; d.xa[XA_HEADER + nb + i] = l >= 0 ? d.cnt_room[l] : 0u; }
 }
@@ -282,8 +330,16 @@ __global__ __launch_bounds__(TPB) void k_unpack_a(Dev d)
     const uint32_t nb = d.n_shared_bld, nr = d.n_shared_room;
     if (i < 5) ctrl->counts[i] = d.xa[i];
     if (i == 5) ctrl->n_riders = d.xa[5];
-    if (i < nb) { const int32_t l = d.shared_bld[i]; if (l >= 0) d.cnt_bld[l] = d.xa[XA_HEADER + i]; }
-    if (i < nr) { const int32_t l = d.shared_room[i]; if (l >= 0) d.cnt_room[l] = d.xa[XA_HEADER + nb + i]; }
+    if (i < nb) {
+        const int32_t l = d.shared_bld[i];
+        const uint32_t tot = d.xa[XA_HEADER + i];
+        if (l >= 0 && tot) { if (d.cnt_bld[l] == 0u) append(d.touched_bld, &ctrl->n_touched_bld, (uint32_t)l); d.cnt_bld[l] = tot; }
+    }
+    if (i < nr) {
+        const int32_t l = d.shared_room[i];
+        const uint32_t tot = d.xa[XA_HEADER + nb + i];
+        if (l >= 0 && tot) { if (d.cnt_room[l] == 0u) append(d.touched_room, &ctrl->n_touched_room, (uint32_t)l); d.cnt_room[l] = tot; }
+    }
 }
 
 __device__ __forceinline__ uint32_t vacc_candidate(const Dev &d, uint32_t i, uint32_t t)
@@ -293,25 +349,57 @@ __device__ __forceinline__ uint32_t vacc_candidate(const Dev &d, uint32_t i, uin
     return (uint32_t)__umul64hi(x, (uint64_t)d.n_global);
 }
 
-// Liveness (eligible bit) of the first VACC_BATCH vaccination candidates, owner computes.
+// Member of citizens_eligible_for_vaccine (simulator.rs:97)?  The set is "Susceptible at the end of
+// the trigger step" (simulator.rs:487-513) minus later bus exposures (:447-449); building exposures
+// and vaccination never remove anybody (Q10).  All of that is recoverable from the state word.
+__device__ __forceinline__ bool eligible(uint32_t st, uint32_t trigger_step)
+{
+    const uint32_t te = st & ST_TE_MASK;
+    if (te == TE_SUSCEPTIBLE || te == TE_VACCINATED) return true;        // only eligible citizens are ever vaccinated
+    if (te >= TE_RECOVERED) return false;
+    return te > trigger_step + TE_BIAS && !(st & ST_BUS_EXPOSED);
+}
+
+// Liveness of the first VACC_BATCH vaccination candidates, owner computes (sharded runs).
 __global__ __launch_bounds__(TPB) void k_pack_b(Dev d)
 {
     const Ctrl *ctrl = d.ctrl;
     const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-    if (i == 0) { d.xb[0] = ctrl->exp_bld; d.xb[1] = ctrl->exp_bus; d.xb[2] = ctrl->elig_count; d.xb[3] = ctrl->error; }
+    const uint32_t t = ctrl->t;
+    // the programme may start in this very step: same test as k_finish
+    const uint32_t total = ctrl->counts[0] + ctrl->counts[1] + ctrl->counts[2] + ctrl->counts[3] + ctrl->counts[4];
+    const bool trig = !ctrl->vacc_active && d.thr_vacc < (double)ctrl->counts[2] / (double)total;
+    const uint32_t tstep = trig ? t : ctrl->trigger_step;
+    if (i == 0) {
+        d.xb[0] = ctrl->exp_bld; d.xb[1] = ctrl->exp_bus;
+        d.xb[2] = trig ? ctrl->n_susceptible - ctrl->exp_bld - ctrl->exp_bus : ctrl->elig_count;
+        d.xb[3] = ctrl->error;
+    }
     if (i < VACC_BATCH) {
-        const uint32_t j = vacc_candidate(d, i, ctrl->t);
+        const uint32_t j = vacc_candidate(d, i, t);
         bool live = false;
-        if (j >= d.id_base && j - d.id_base < d.n) live = d.state[j - d.id_base] & ST_ELIGIBLE;
+        if ((ctrl->have_elig || trig) && j >= d.id_base && j - d.id_base < d.n) live = eligible(d.state[j - d.id_base], tstep);
         const unsigned long long m = __ballot(live);
         if ((threadIdx.x & 63u) == 0) { d.xb[XB_HEADER + (i >> 5)] = (uint32_t)m; d.xb[XB_HEADER + (i >> 5) + 1] = (uint32_t)(m >> 32); }
     }
 }
 
+// Vaccination bookkeeping for one citizen set to Vaccinated (simulator.rs:551).
+__device__ __forceinline__ void vaccinate(const Dev &d, Ctrl *ctrl, uint32_t c)
+{
+    const uint32_t st = d.state[c], te = st & ST_TE_MASK;
+    if (te == TE_VACCINATED) return;                                     // chosen again: ids are never removed (Q10)
+    if (te == TE_SUSCEPTIBLE) atomicSub(&ctrl->n_susceptible, 1u);
+    else if (te == TE_RECOVERED) atomicSub(&ctrl->n_recovered_sentinel, 1u);
+    else atomicSub(&d.hist[te], 1u);                                     // an Exposed/Infected/Recovered citizen is relabelled
+    atomicAdd(&ctrl->n_vaccinated, 1u);
+    d.state[c] = (uint16_t)((st & ~ST_TE_MASK) | TE_VACCINATED);
+}
+
 // ---------------------------------------------------------------------------------- k_finish
 // apply_interventions (simulator.rs:455-556): InterventionStatus::update_status
-// (interventions.rs:110-184), the vaccination draw (simulator.rs:524-553), and the
-// StatisticEntry of the step (statistics.rs:208-215, adjusted by citizen_exposed :275-287).
+// (interventions.rs:110-184), the vaccination draw (simulator.rs:524-553), the StatisticEntry of the
+// step (statistics.rs:208-215, adjusted by citizen_exposed :275-287), and the hand-over to step t+1.
 #define FIN_TPB 1024
 __global__ __launch_bounds__(FIN_TPB) void k_finish(Dev d, int sharded)
 {
@@ -319,27 +407,42 @@ __global__ __launch_bounds__(FIN_TPB) void k_finish(Dev d, int sharded)
     __shared__ uint32_t tab_idx[VACC_TABLE];
     __shared__ uint32_t wsum[FIN_TPB / 64];
     __shared__ uint32_t s_total;
+    __shared__ uint32_t cen[5];
     Ctrl *ctrl = d.ctrl;
     if (ctrl->finished) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t t = ctrl->t;
-    const uint32_t total = ctrl->counts[0] + ctrl->counts[1] + ctrl->counts[2] + ctrl->counts[3] + ctrl->counts[4];
-    const double x = (double)ctrl->counts[2] / (double)total;            // infected_percentage, statistics.rs:252
+    uint32_t at_work, bus_dir;
+    schedule(d, ctrl, t, at_work, bus_dir);
+    if (sharded) { if (tid < 5) cen[tid] = ctrl->counts[tid]; __syncthreads(); }     // global census from exchange A
+    else census_block(d, ctrl, t, cen);
+    const uint32_t total = cen[0] + cen[1] + cen[2] + cen[3] + cen[4];
+    const double x = (double)cen[2] / (double)total;                     // infected_percentage, statistics.rs:252
     const bool trig = !ctrl->vacc_active && d.thr_vacc < x;
     const bool have = ctrl->have_elig || trig;
-    // sharded: totals over all shards come from exchange buffer B, the ctrl fields stay per-shard
-    const uint32_t elig_count = sharded ? d.xb[2] : ctrl->elig_count;
+    const uint32_t tstep = trig ? t : ctrl->trigger_step;
+    // totals over all shards come from exchange buffer B when sharded, the ctrl fields stay per-shard
     const uint32_t exp_bld = sharded ? d.xb[0] : ctrl->exp_bld;
     const uint32_t exp_bus = sharded ? d.xb[1] : ctrl->exp_bus;
+    const uint32_t local_elig = trig ? ctrl->n_susceptible - ctrl->exp_bld - ctrl->exp_bus : ctrl->elig_count;
+    const uint32_t elig_count = sharded ? d.xb[2] : local_elig;
+    const uint32_t n_riders = sharded ? ctrl->n_riders : (bus_dir ? d.n_pt : 0u);
+    __syncthreads();
+    // this step's exposures enter the books before anybody is vaccinated
+    if (tid == 0) {
+        const uint32_t mine = ctrl->exp_bld + ctrl->exp_bus;
+        ctrl->n_susceptible -= mine;
+        d.hist[t + TE_BIAS] += mine;
+        d.log_off[t + TE_BIAS + 1u] = ctrl->log_len;
+        if (trig) ctrl->elig_count = local_elig;
+    }
+    __syncthreads();
     uint32_t vacc_now = 0;
-
     if (have) {
         if (elig_count <= d.vaccination_rate) {
             // choose_multiple hands back the whole set (simulator.rs:525-527)
-            for (uint32_t c = tid; c < d.n; c += FIN_TPB) {
-                const uint32_t st = d.state[c];
-                if (st & ST_ELIGIBLE) d.state[c] = (uint16_t)((st & ~ST_TE_MASK) | TE_VACCINATED);
-            }
+            for (uint32_t c = tid; c < d.n; c += FIN_TPB)
+                if (eligible(d.state[c], tstep)) vaccinate(d, ctrl, c);
             vacc_now = elig_count;
         } else {
             const uint32_t k = d.vaccination_rate;
@@ -353,7 +456,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_finish(Dev d, int sharded)
                     const uint32_t i = base + tid * 4u + q;
                     j[q] = vacc_candidate(d, i, t);
                     if (sharded) live[q] = (d.xb[XB_HEADER + ((i - base) >> 5)] >> ((i - base) & 31u)) & 1u;
-                    else live[q] = d.state[j[q]] & ST_ELIGIBLE;
+                    else live[q] = eligible(d.state[j[q]], tstep);
                     slot[q] = 0;
                     if (live[q]) {
                         uint32_t sl = (j[q] * 2654435761u) >> 18;        // 14 bits
@@ -387,10 +490,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_finish(Dev d, int sharded)
                     if (first[q]) {
                         if (pos < k) {
                             const uint32_t g = j[q];
-                            if (g >= d.id_base && g - d.id_base < d.n) {
-                                const uint32_t st = d.state[g - d.id_base];
-                                d.state[g - d.id_base] = (uint16_t)((st & ~ST_TE_MASK) | TE_VACCINATED);  // unconditional, simulator.rs:551
-                            }
+                            if (g >= d.id_base && g - d.id_base < d.n) vaccinate(d, ctrl, g - d.id_base);   // unconditional, simulator.rs:551
                         }
                         pos++;
                     }
@@ -405,15 +505,21 @@ __global__ __launch_bounds__(FIN_TPB) void k_finish(Dev d, int sharded)
             vacc_now = already;
         }
     }
+    // forget this step's marks
+    const uint32_t nb = ctrl->n_touched_bld, nr = ctrl->n_touched_room, nrt = ctrl->n_touched_route, nrb = ctrl->n_touched_route_big;
+    for (uint32_t i = tid; i < nb; i += FIN_TPB) d.cnt_bld[d.touched_bld[i]] = 0u;
+    for (uint32_t i = tid; i < nr; i += FIN_TPB) d.cnt_room[d.touched_room[i]] = 0u;
+    for (uint32_t i = tid; i < nrt; i += FIN_TPB) d.route_flag[d.touched_route[i]] = 0u;
+    for (uint32_t i = tid; i < nrb; i += FIN_TPB) d.route_flag[d.touched_route_big[i]] = 0u;
     __syncthreads();
     if (tid == 0) {
         const uint32_t exps = exp_bld + exp_bus;
         if (sharded) ctrl->error |= d.xb[3];
         esim_step_result r;
         r.time_step = t;
-        if (exps > ctrl->counts[0]) ctrl->error = (uint32_t)(-ESIM_ESIM);   // citizen_exposed underflow
-        r.susceptible = ctrl->counts[0] - exps; r.exposed = ctrl->counts[1] + exps;
-        r.infected = ctrl->counts[2]; r.recovered = ctrl->counts[3]; r.vaccinated = ctrl->counts[4];
+        if (exps > cen[0]) ctrl->error = (uint32_t)(-ESIM_ESIM);          // citizen_exposed underflow, statistics.rs:275-287
+        r.susceptible = cen[0] - exps; r.exposed = cen[1] + exps;
+        r.infected = cen[2]; r.recovered = cen[3]; r.vaccinated = cen[4];
         r.exposures_building = exp_bld; r.exposures_bus = exp_bus;
         // InterventionStatus::update_status, interventions.rs:110-184 (all comparisons strict)
         const uint32_t lockdown = d.thr_lockdown < x ? 1u : 0u;             // :116-128
@@ -423,32 +529,26 @@ __global__ __launch_bounds__(FIN_TPB) void k_finish(Dev d, int sharded)
             if (x < d.thr_mask_pt) mask = ESIM_MASK_NONE;
             else if (d.thr_mask_all < x) mask = ESIM_MASK_EVERYWHERE;
         } else if (x < d.thr_mask_all) mask = ESIM_MASK_PUBLIC_TRANSPORT;
-        // the direction everyone on a bus travels in, citizen.rs:179-204 with the lockdown used by THIS step
-        if (!ctrl->lockdown) {
-            const uint32_t h = t % 24u;
-            if (h == d.start_hour - 1u) ctrl->bus_dir = 1u;
-            else if (h == d.start_hour) ctrl->bus_dir = 0u;
-            else if (h == d.end_hour - 1u) ctrl->bus_dir = 2u;
-            else ctrl->bus_dir = 0u;
-        }
+        ctrl->at_work = at_work; ctrl->bus_dir = bus_dir;
         ctrl->lockdown = lockdown; ctrl->mask = mask;
-        if (trig) { ctrl->vacc_active = 1u; ctrl->have_elig = 1u; }
+        if (trig) { ctrl->vacc_active = 1u; ctrl->have_elig = 1u; ctrl->trigger_step = t; }
         r.lockdown = lockdown; r.vaccination_active = ctrl->vacc_active; r.mask_status = mask;
-        r.n_riders = ctrl->n_riders; r.vaccinated_now = vacc_now; r.eligible_count = have ? elig_count : 0u;
+        r.n_riders = n_riders; r.vaccinated_now = vacc_now; r.eligible_count = have ? elig_count : 0u;
         r.disease_exists = (r.exposed != 0u || r.infected != 0u || r.susceptible != 0u) ? 1u : 0u;   // statistics.rs:289-291
         r.reserved = 0u;
         if (t <= d.max_steps) d.records[t] = r;
         ctrl->steps_done = t;
         if (!r.disease_exists && ctrl->stop_when_done) ctrl->finished = 1u;
+        ctrl->n_touched_bld = 0u; ctrl->n_touched_room = 0u; ctrl->n_touched_route = 0u; ctrl->n_touched_route_big = 0u;
+        ctrl->exp_bld = 0u; ctrl->exp_bus = 0u; ctrl->n_riders = 0u;
         for (int i = 0; i < 5; ++i) ctrl->counts[i] = 0u;
-        ctrl->n_riders = 0u; ctrl->exp_bld = 0u; ctrl->exp_bus = 0u;
         ctrl->t = t + 1u;
     }
 }
 
-// Reference-shaped view of the state word (esim_download_state).
+// Reference-shaped view of the state (esim_download_state).
 __global__ __launch_bounds__(TPB) void k_decode_state(Dev d, uint8_t *status, uint16_t *timer, uint32_t *cur,
-                                                      uint8_t *on_bus, uint8_t *eligible)
+                                                      uint8_t *on_bus, uint8_t *elig)
 {
     const Ctrl *ctrl = d.ctrl;
     const uint32_t t = ctrl->t - 1u;             // last completed step
@@ -462,8 +562,8 @@ __global__ __launch_bounds__(TPB) void k_decode_state(Dev d, uint8_t *status, ui
         }
         if (status) status[c] = (uint8_t)cls;
         if (timer) timer[c] = (uint16_t)tm;
-        if (cur) cur[c] = ((st & ST_AT_WORK) && (fl & FL_HAS_WORK)) ? d.work[c] : d.home[c];
-        if (on_bus) on_bus[c] = (st & ST_ON_BUS) ? (uint8_t)ctrl->bus_dir : 0;
-        if (eligible) eligible[c] = (st & ST_ELIGIBLE) ? 1 : 0;
+        if (cur) cur[c] = (ctrl->at_work && (fl & FL_HAS_WORK)) ? d.work[c] : d.home[c];
+        if (on_bus) on_bus[c] = (fl & FL_USES_PT) ? (uint8_t)ctrl->bus_dir : 0;
+        if (elig) elig[c] = (ctrl->have_elig && eligible(st, ctrl->trigger_step)) ? 1 : 0;
     }
 }

@@ -98,10 +98,10 @@ class ShardedSimulator:
         _lib.check(self.lib.esim_enable_kernel_timing(self._ctx, int(stride)), self._ctx)
 
     def kernel_timings(self):
-        ms = (C.c_double * 2)()
+        ms = (C.c_double * 3)()
         n = C.c_uint32(0)
         _lib.check(self.lib.esim_kernel_timings(self._ctx, ms, C.byref(n)), self._ctx)
-        return {"tick_ms": ms[0], "expose_ms": ms[1], "launches": n.value}
+        return {"k_infected_ms": ms[0], "k_expose_ms": ms[1], "k_finish_ms": ms[2], "launches": n.value}
 
     def close(self):
         if self._ctx:

@@ -137,10 +137,10 @@ class Simulator:
         _lib.check(self.lib.esim_enable_kernel_timing(self._ctx, int(stride)), self._ctx)
 
     def kernel_timings(self):
-        ms = (C.c_double * 2)()
+        ms = (C.c_double * 3)()
         n = C.c_uint32(0)
         _lib.check(self.lib.esim_kernel_timings(self._ctx, ms, C.byref(n)), self._ctx)
-        return {"tick_ms": ms[0], "expose_ms": ms[1], "launches": n.value}
+        return {"k_infected_ms": ms[0], "k_expose_ms": ms[1], "k_finish_ms": ms[2], "launches": n.value}
 
     def enable_phase_timing(self, on=True):
         _lib.check(self.lib.esim_enable_phase_timing(self._ctx, int(on)), self._ctx)

@@ -174,11 +174,13 @@ int  esim_download_state(esim_ctx *ctx, uint8_t *status, uint16_t *timer,
 int  esim_enable_phase_timing(esim_ctx *ctx, int enable);
 int  esim_phase_timings(esim_ctx *ctx, double out[4]);
 
-/* Mean duration (ms) of the dominant per-citizen kernels over the launches since the last
- * call, measured with hipEvents on the context's stream when kernel timing is enabled.
- *   out_ms[0] tick kernel, out_ms[1] exposure kernel; out_n = launches averaged. */
+/* Mean duration (ms) of the three kernels of a time step over the steps timed since the last call,
+ * measured with hipEvents on the context's stream.  esim_enable_kernel_timing(ctx, n) brackets the
+ * kernels of every n-th step (n = 0: off).
+ *   out_ms[0] k_infected (generate_exposures), out_ms[1] k_expose (apply_exposures),
+ *   out_ms[2] k_finish (apply_interventions + census); out_n = steps averaged. */
 int  esim_enable_kernel_timing(esim_ctx *ctx, int enable);
-int  esim_kernel_timings(esim_ctx *ctx, double out_ms[2], uint32_t *out_n);
+int  esim_kernel_timings(esim_ctx *ctx, double out_ms[3], uint32_t *out_n);
 
 const char *esim_last_error(const esim_ctx *ctx);   /* ctx may be NULL: last esim_create error */
 void esim_destroy(esim_ctx *ctx);

@@ -51,6 +51,8 @@ def main():
         for k, v in traffic.items():
             short = k.split("(")[0]
             tj[short + "_bytes_per_launch"] = v["hbm_bytes_corrected"]
+        tj["step_bytes_per_launch"] = sum(v["hbm_bytes_corrected"] for k, v in traffic.items()
+                                          if k.split("(")[0] in ("k_infected", "k_expose", "k_finish"))
         with open(os.path.join(here, "traffic.json"), "w") as fh:
             json.dump(tj, fh, indent=1)
     with open(os.path.join(here, "%s_summary.json" % tag), "w") as fh:
