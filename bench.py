@@ -2,10 +2,13 @@
 """bench.py -- citizen-timesteps/sec of the per-timestep Citizen update loop on MI355X.
 
 A "step" is one time step (Simulator::step, sim/src/simulator.rs:131) over the whole synthetic
-population.  Workload: BASELINE.json configs[4], the 64 M-citizen synthetic UK (preset `uk64m`,
-interventions enabled) -- it fits one GPU, so N=1 runs all of it and N>1 shards the same population by
-Output Area (strong scaling), one process per GPU, two small SUM all-reduces per step over RCCL.
-Population build and upload are outside the timed region; inputs are resident in HBM when it starts.
+population.  Workload: BASELINE.json configs[4], the 64 M-citizen synthetic UK (preset `uk64m`, 10 seeds,
+interventions enabled) -- it fits one GPU, so N=1 runs all of it.  For N>1 the per-GPU work is kept fixed
+(weak scaling): a world of N x 64 M citizens / N x 290 000 Output Areas, Output Areas sharded by whole school
+catchments, one process per GPU; every rank generates only its own shard.  Shards that share no building
+exchange one 96-entry SUM all-reduce per 96 steps (decoupled mode) until a vaccination
+programme starts, then two small all-reduces per step.  Population build and upload are outside the timed
+region; inputs are resident in HBM when it starts.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -47,6 +50,7 @@ def main():
     ap.add_argument("--preset", default="uk64m", help="synthetic population preset (default: the benchmark workload)")
     ap.add_argument("--cpu-steps", type=int, default=24, help="time steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--timing-stride", type=int, default=16, help="bracket the per-citizen kernels with HIP events every n-th step")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -61,15 +65,24 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if os.environ.get("ESIM_BENCH_SAME_DEVICE"):      # rehearsal of the multi-rank path on a one-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     steps, warmup = args.steps, min(args.warmup, args.steps)
-    pop = Population.synthetic(args.preset)
+    # weak scaling: the world is `world` times the preset, this rank generates its own shard of it
+    spec = _lib.SynthSpec()
+    _lib.check(_lib.load().esim_synth_preset(args.preset.encode(), __import__("ctypes").byref(spec)))
+    n_total, n_areas = spec.n_citizens * world, spec.n_areas * world
+    pop = Population.synthetic_shard(rank, world, args.preset, n_citizens=n_total, n_areas=n_areas)
     params = _lib.default_params(max_steps=max(steps, warmup, 1))
-    sim = ShardedSimulator(pop, rank, world, params, device_index=local_rank)
+    sim = ShardedSimulator(None, rank, world, params, device_index=local_rank, shard_population=pop)
 
     def fence():
         sim.synchronize()
@@ -95,7 +108,6 @@ def main():
     rec = sim.records(1, steps)
 
     if rank == 0:
-        n_total = pop.n_citizens
         n_local = sim.population.n_citizens
         value = n_total * steps / elapsed
         # The three kernels of a time step together carry SURVEY.md 8(d)'s 26 algorithmic bytes per
@@ -113,11 +125,13 @@ def main():
         out = {
             "metric": "citizen-timesteps/sec", "value": value, "unit": "citizen-timesteps/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u16/u32 state, u64 Philox thresholds",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16/u32 state, u64 Philox thresholds",
             "data": "synthetic",
-            "config": {"workload": "%s: %d citizens, %d Output Areas, %d steps, interventions on; Output Areas sharded over %d GPU(s)"
-                                   % (args.preset, n_total, pop.n_areas, steps, world),
-                       "citizens_per_gpu": n_local, "seed": int(params.seed)},
+            "config": {"workload": "%s x %d: %d citizens, %d Output Areas, %d seeds, %d steps, interventions on; "
+                                   "Output Areas sharded by school catchment over %d GPU(s)"
+                                   % (args.preset, world, n_total, n_areas, spec.n_seeds, steps, world),
+                       "citizens_per_gpu": n_local, "seed": int(params.seed),
+                       "decoupled_steps": sim.free_steps, "coupled_steps": sim.coupled_steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_infected+k_expose+k_finish (one time step); longest: " + dom,

@@ -82,11 +82,11 @@ class SynthSpec(C.Structure):
 SYMBOLS = [
     "esim_default_params", "esim_create", "esim_upload_population", "esim_reset", "esim_step",
     "esim_run", "esim_step_begin", "esim_step_exposures", "esim_step_finish",
-    "esim_exchange_buffer", "esim_read_records", "esim_stream", "esim_set_stream",
+    "esim_exchange_buffer", "esim_future_infected", "esim_run_free", "esim_read_records", "esim_stream", "esim_set_stream",
     "esim_set_exchange_buffer", "esim_synchronize",
     "esim_download_state", "esim_enable_phase_timing", "esim_phase_timings",
     "esim_enable_kernel_timing", "esim_kernel_timings", "esim_last_error", "esim_destroy",
-    "esim_threshold_lut", "esim_synth_preset", "esim_synth_create", "esim_synth_free",
+    "esim_threshold_lut", "esim_synth_preset", "esim_synth_create", "esim_synth_create_shard", "esim_synth_free",
     "esim_shard_population",
 ]
 
@@ -115,6 +115,8 @@ def load():
         "esim_step_exposures": (C.c_int, [vp]),
         "esim_step_finish": (C.c_int, [vp, C.POINTER(StepResult)]),
         "esim_exchange_buffer": (C.c_int, [vp, C.c_int, pvp, C.POINTER(C.c_size_t)]),
+        "esim_future_infected": (C.c_int, [vp]),
+        "esim_run_free": (C.c_int, [vp, C.c_uint32]),
         "esim_read_records": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(StepResult)]),
         "esim_stream": (C.c_int, [vp, pvp]),
         "esim_set_stream": (C.c_int, [vp, vp]),
@@ -130,6 +132,7 @@ def load():
         "esim_threshold_lut": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_uint64)]),
         "esim_synth_preset": (C.c_int, [C.c_char_p, C.POINTER(SynthSpec)]),
         "esim_synth_create": (C.c_int, [C.POINTER(SynthSpec), C.POINTER(PopulationStruct)]),
+        "esim_synth_create_shard": (C.c_int, [C.POINTER(SynthSpec), C.c_uint32, C.c_uint32, C.POINTER(PopulationStruct)]),
         "esim_synth_free": (None, [C.POINTER(PopulationStruct)]),
         "esim_shard_population": (C.c_int, [C.POINTER(PopulationStruct), _u32p, C.c_uint32, C.c_uint32,
                                             C.POINTER(PopulationStruct)]),

@@ -27,7 +27,7 @@ struct esim_ctx_impl {
     std::vector<uint32_t> init_log;       // distinct seeds
     size_t cnt_bytes = 0;
     uint32_t n_routes = 0;
-    size_t xa_n = 0, xb_n = 0;
+    size_t xa_n = 0, xb_n = 0, xf_n = 0;
     uint32_t host_t = 1;          // next time step to enqueue
     // device allocations
     std::vector<void *> allocs;
@@ -331,6 +331,9 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     c->xb_n = XB_HEADER + VACC_BATCH / 32u;
     if ((rc = dev_alloc(c, &d.xa, c->xa_n))) return rc;
     if ((rc = dev_alloc(c, &d.xb, c->xb_n))) return rc;
+    c->xf_n = std::min<uint32_t>(FREE_MAX, c->P.exposed_time + 1u);
+    if ((rc = dev_alloc(c, &d.xf, FREE_MAX))) return rc;
+    HIP_TRY(c, hipMemset(d.xf, 0, sizeof(uint32_t) * FREE_MAX));
     HIP_TRY(c, hipMemset(d.xa, 0, sizeof(uint32_t) * c->xa_n));
     HIP_TRY(c, hipMemset(d.xb, 0, sizeof(uint32_t) * c->xb_n));
 
@@ -406,11 +409,12 @@ int enqueue_exposures(esim_ctx_impl *c, bool time_kernel)
     return ESIM_OK;
 }
 
-int enqueue_finish(esim_ctx_impl *c, bool time_kernel)
+int enqueue_finish(esim_ctx_impl *c, bool time_kernel, int mode = -1)
 {
     Dev &d = c->d;
+    if (mode < 0) mode = d.n_shards > 1 ? 1 : 0;
     if (time_kernel) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 4], c->stream));
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(FIN_TPB), 0, c->stream, d, d.n_shards > 1 ? 1 : 0);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(FIN_TPB), 0, c->stream, d, mode);
     if (time_kernel) { HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 5], c->stream)); c->kev_used += 6; }
     if (c->phase_timing) {
         HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
@@ -525,13 +529,47 @@ extern "C" int esim_run(esim_ctx *ctx, uint32_t n_steps, int stop_when_done, esi
     return ESIM_OK;
 }
 
+extern "C" int esim_future_infected(esim_ctx *ctx)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "no population uploaded");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    hipLaunchKernelGGL(k_future, dim3(1), dim3(TPB), 0, c->stream, c->d, (uint32_t)c->xf_n);
+    HIP_TRY(c, hipGetLastError());
+    return ESIM_OK;
+}
+
+extern "C" int esim_run_free(esim_ctx *ctx, uint32_t n_steps)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    int rc = check_budget(c, n_steps);
+    if (rc) return rc;
+    if (n_steps > c->xf_n) return fail(c, ESIM_EINVAL, "esim_run_free: more steps than the future vector covers");
+    if (c->d.n_shared_bld || c->d.n_shared_room) return fail(c, ESIM_ESTATE, "esim_run_free: shards that share buildings need the coupled steps");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    for (uint32_t s = 0; s < n_steps; ++s) {
+        const bool tk = want_kernel_timing(c);
+        if (c->phase_timing) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+        if (tk) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 0], c->stream));
+        hipLaunchKernelGGL(k_infected, dim3(c->grid_infected), dim3(TPB), 0, c->stream, c->d);
+        if (tk) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 1], c->stream));
+        if (c->phase_timing) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+        if (tk) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 2], c->stream));
+        hipLaunchKernelGGL(k_expose, dim3(c->grid_expose), dim3(TPB), 0, c->stream, c->d);
+        if (tk) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 3], c->stream));
+        if (c->phase_timing) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+        if ((rc = enqueue_finish(c, tk, 2))) return rc;
+    }
+    return ESIM_OK;
+}
+
 extern "C" int esim_exchange_buffer(esim_ctx *ctx, int which, void **device_ptr, size_t *n_u32)
 {
     esim_ctx_impl *c = CTX(ctx);
     if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "no population uploaded");
-    if (which != 0 && which != 1) return fail(c, ESIM_EINVAL, "esim_exchange_buffer: which must be 0 or 1");
-    if (device_ptr) *device_ptr = which ? (void *)c->d.xb : (void *)c->d.xa;
-    if (n_u32) *n_u32 = which ? c->xb_n : c->xa_n;
+    if (which < 0 || which > 2) return fail(c, ESIM_EINVAL, "esim_exchange_buffer: which must be 0, 1 or 2");
+    if (device_ptr) *device_ptr = which == 2 ? (void *)c->d.xf : which ? (void *)c->d.xb : (void *)c->d.xa;
+    if (n_u32) *n_u32 = which == 2 ? c->xf_n : which ? c->xb_n : c->xa_n;
     return ESIM_OK;
 }
 
@@ -570,10 +608,10 @@ extern "C" int esim_set_exchange_buffer(esim_ctx *ctx, int which, void *device_p
 {
     esim_ctx_impl *c = CTX(ctx);
     if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "no population uploaded");
-    if ((which != 0 && which != 1) || !device_ptr) return fail(c, ESIM_EINVAL, "esim_set_exchange_buffer: bad argument");
+    if (which < 0 || which > 2 || !device_ptr) return fail(c, ESIM_EINVAL, "esim_set_exchange_buffer: bad argument");
     HIP_TRY(c, hipSetDevice(c->P.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (which) c->d.xb = (uint32_t *)device_ptr; else c->d.xa = (uint32_t *)device_ptr;
+    if (which == 2) c->d.xf = (uint32_t *)device_ptr; else if (which) c->d.xb = (uint32_t *)device_ptr; else c->d.xa = (uint32_t *)device_ptr;
     return ESIM_OK;
 }
 

@@ -55,7 +55,8 @@ struct Ctrl {
     uint32_t exp_bld, exp_bus;
     uint32_t counts[5];         // census of the step in flight (global when sharded, after unpack)
     uint32_t n_riders;
-    uint32_t pad[3];
+    uint32_t free_base;         // first step of the current free-running batch (decoupled sharded mode)
+    uint32_t pad[2];
 };
 
 struct Dev {
@@ -98,7 +99,7 @@ struct Dev {
     uint32_t n_shards;
     uint32_t n_shared_bld, n_shared_room;
     const int32_t *shared_bld, *shared_room;
-    uint32_t *xa, *xb;                  // exchange buffers A and B
+    uint32_t *xa, *xb, *xf;             // exchange buffers A, B and the future-infected vector
 };
 
 // exchange buffer A: [0..4] census, [5] riders, then shared building counts, then shared room counts
@@ -106,3 +107,5 @@ struct Dev {
 // exchange buffer B: [0] building exposures, [1] bus exposures, [2] eligible count, [3] error, then
 // VACC_BATCH/32 words of candidate liveness bits
 #define XB_HEADER 8u
+// exchange buffer F: Infected census of the next FREE_MAX steps (decoupled sharded mode)
+#define FREE_MAX 96u

@@ -384,6 +384,24 @@ __global__ __launch_bounds__(TPB) void k_pack_b(Dev d)
     }
 }
 
+// Decoupled sharded mode.  A citizen exposed in step t is Infected no earlier than step t + exposed_time + 1,
+// so after step t0 the Infected census of steps t0+1 .. t0+exposed_time+1 is already fixed (as long as nobody is
+// vaccinated).  Shards therefore exchange that vector once per batch instead of a census every step; the
+// intervention decisions of the batch (interventions.rs:110-184 needs only the infected fraction) then read it.
+__global__ __launch_bounds__(TPB) void k_future(Dev d, uint32_t n_ahead)
+{
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t t0 = ctrl->t;                                           // first step of the batch
+    for (uint32_t j = threadIdx.x; j < n_ahead; j += TPB) {
+        const int hi = (int)(t0 + j + TE_BIAS) - (int)d.exposed_time - 1;
+        const int lo = hi - (int)d.infected_time;
+        uint32_t s = 0;
+        for (int k = lo < 0 ? 0 : lo; k <= hi; ++k) s += d.hist[k];
+        d.xf[j] = s;
+    }
+    if (threadIdx.x == 0) ctrl->free_base = t0;
+}
+
 // Vaccination bookkeeping for one citizen set to Vaccinated (simulator.rs:551).
 __device__ __forceinline__ void vaccinate(const Dev &d, Ctrl *ctrl, uint32_t c)
 {
@@ -414,11 +432,21 @@ __global__ __launch_bounds__(FIN_TPB) void k_finish(Dev d, int sharded)
     const uint32_t t = ctrl->t;
     uint32_t at_work, bus_dir;
     schedule(d, ctrl, t, at_work, bus_dir);
+    // sharded: 0 one shard; 1 coupled (global census from exchange A); 2 free-running batch (local census,
+    // the global Infected count of this step comes from the exchanged future vector)
+    const bool free_run = sharded == 2;
+    if (free_run) sharded = 0;
     if (sharded) { if (tid < 5) cen[tid] = ctrl->counts[tid]; __syncthreads(); }     // global census from exchange A
     else census_block(d, ctrl, t, cen);
     const uint32_t total = cen[0] + cen[1] + cen[2] + cen[3] + cen[4];
-    const double x = (double)cen[2] / (double)total;                     // infected_percentage, statistics.rs:252
-    const bool trig = !ctrl->vacc_active && d.thr_vacc < x;
+    const double x = free_run ? (double)d.xf[t - ctrl->free_base] / (double)d.n_global
+                              : (double)cen[2] / (double)total;          // infected_percentage, statistics.rs:252
+    bool trig = !ctrl->vacc_active && d.thr_vacc < x;
+    if (free_run && (trig || ctrl->have_elig || t - ctrl->free_base >= FREE_MAX)) {
+        // the host must switch to the coupled mode before the vaccination programme starts
+        if (tid == 0) ctrl->error = (uint32_t)(-ESIM_ESTATE);
+        trig = false;
+    }
     const bool have = ctrl->have_elig || trig;
     const uint32_t tstep = trig ? t : ctrl->trigger_step;
     // totals over all shards come from exchange buffer B when sharded, the ctrl fields stay per-shard

@@ -64,9 +64,13 @@ extern "C" int esim_synth_preset(const char *name, esim_synth_spec *out)
     return ESIM_OK;
 }
 
-extern "C" int esim_synth_create(const esim_synth_spec *spec, esim_population *out)
+// Generates the citizens of the school catchments [S*shard/n_shards, S*(shard+1)/n_shards) of the world
+// described by `spec` (all of it for n_shards == 1).  Every random draw is keyed by GLOBAL area / citizen
+// indices, so the shards of a world are exactly the pieces of the whole.  Catchments are closed under
+// home, work and school membership, hence such a shard shares no building with any other shard.
+static int synth_generate(const esim_synth_spec *spec, uint32_t shard, uint32_t n_shards, esim_population *out)
 {
-    if (!spec || !out || spec->n_areas == 0 || spec->n_citizens == 0) return ESIM_EINVAL;
+    if (!spec || !out || spec->n_areas == 0 || spec->n_citizens == 0 || n_shards == 0 || shard >= n_shards) return ESIM_EINVAL;
     const uint32_t N = spec->n_citizens, A = spec->n_areas;
     Rng rng{ spec->seed };
 
@@ -86,18 +90,28 @@ extern "C" int esim_synth_create(const esim_synth_spec *spec, esim_population *o
         for (uint32_t a = 0; a < A; ++a) area_off[a + 1] = area_off[a] + pop[a];
     }
 
-    // ---- citizen attributes
-    std::vector<uint32_t> home(N), work(N), room(N, ESIM_NO_ROOM);
-    std::vector<uint8_t> flags(N), occ(N);
-    std::vector<uint16_t> age(N);
+    // ---- schools: contiguous catchments of areas; the shard is a run of whole catchments
+    uint32_t n_schools = (uint32_t)std::max<int64_t>(1, std::llround((double)N / std::max(1u, spec->citizens_per_school)));
+    n_schools = std::min(n_schools, A);
+    if (n_shards > n_schools) return ESIM_EINVAL;
+    auto school_area_begin = [&](uint32_t s) { return (uint32_t)(((uint64_t)A * s) / n_schools); };
+    const uint32_t s_lo = (uint32_t)(((uint64_t)n_schools * shard) / n_shards);
+    const uint32_t s_hi = (uint32_t)(((uint64_t)n_schools * (shard + 1)) / n_shards);
+    const uint32_t a_lo = school_area_begin(s_lo), a_hi = school_area_begin(s_hi);
+    const uint32_t c_lo = area_off[a_lo], c_hi = area_off[a_hi], n = c_hi - c_lo;
+
+    // ---- citizen attributes (local index = global index - c_lo)
+    std::vector<uint32_t> home(n), work(n), room(n, ESIM_NO_ROOM);
+    std::vector<uint8_t> flags(n), occ(n);
+    std::vector<uint16_t> age(n);
     enum { OCC_STUDENT = 9, OCC_TEACHING = 8 };   // OccupationType::get_index, citizen.rs:312-324
-    std::vector<uint8_t> wfh(N);
-    for (uint32_t c = 0; c < N; ++c) {
-        philox_out o = rng.block(c, 0, DOM_CITIZEN);
+    std::vector<uint8_t> wfh(n);
+    for (uint32_t c = 0; c < n; ++c) {
+        philox_out o = rng.block(c_lo + c, 0, DOM_CITIZEN);
         age[c] = (uint16_t)(((uint64_t)o.w0 * 91) >> 32);
         uint8_t f = 0;
         if (Rng::u(o.w1) < spec->p_public_transport) f |= ESIM_FLAG_USES_PUBLIC_TRANSPORT;
-        philox_out o2 = rng.block(c, 1, DOM_CITIZEN);
+        philox_out o2 = rng.block(c_lo + c, 1, DOM_CITIZEN);
         if (Rng::u(o2.w0) < spec->p_mask_compliant) f |= ESIM_FLAG_MASK_COMPLIANT;
         flags[c] = f;
         if (age[c] < 18) { occ[c] = OCC_STUDENT; wfh[c] = 0; }
@@ -109,13 +123,9 @@ extern "C" int esim_synth_create(const esim_synth_spec *spec, esim_population *o
         }
     }
 
-    // ---- schools: contiguous catchments of areas
-    uint32_t n_schools = (uint32_t)std::max<int64_t>(1, std::llround((double)N / std::max(1u, spec->citizens_per_school)));
-    n_schools = std::min(n_schools, A);
-    auto school_area_begin = [&](uint32_t s) { return (uint32_t)(((uint64_t)A * s) / n_schools); };
     std::vector<uint32_t> school_host_area(n_schools), school_building(n_schools);
     std::vector<int32_t> area_hosts_school(A, -1);
-    for (uint32_t s = 0; s < n_schools; ++s) {
+    for (uint32_t s = s_lo; s < s_hi; ++s) {
         uint32_t b = school_area_begin(s), e = school_area_begin(s + 1);
         school_host_area[s] = b + (e - b) / 2;
         area_hosts_school[school_host_area[s]] = (int32_t)s;
@@ -123,9 +133,9 @@ extern "C" int esim_synth_create(const esim_synth_spec *spec, esim_population *o
 
     // ---- buildings area by area: households, workplaces, (school)
     std::vector<uint32_t> bld_area; std::vector<uint8_t> bld_type;
-    bld_area.reserve(N / 2); bld_type.reserve(N / 2);
-    for (uint32_t a = 0; a < A; ++a) {
-        const uint32_t c0 = area_off[a], c1 = area_off[a + 1];
+    bld_area.reserve(n / 2); bld_type.reserve(n / 2);
+    for (uint32_t a = a_lo; a < a_hi; ++a) {
+        const uint32_t c0 = area_off[a] - c_lo, c1 = area_off[a + 1] - c_lo;
         philox_out oa = rng.block(a, 1, DOM_AREA);
         const uint32_t hh = 2 + (uint32_t)(((uint64_t)oa.w0 * 4) >> 32);     // household size 2..5
         for (uint32_t c = c0; c < c1; ++c) {
@@ -157,8 +167,8 @@ extern "C" int esim_synth_create(const esim_synth_spec *spec, esim_population *o
 
     // ---- school rooms (School::with_students_and_teachers, building.rs:346-443)
     std::vector<uint32_t> room_bld;
-    for (uint32_t s = 0; s < n_schools; ++s) {
-        const uint32_t c0 = area_off[school_area_begin(s)], c1 = area_off[school_area_begin(s + 1)];
+    for (uint32_t s = s_lo; s < s_hi; ++s) {
+        const uint32_t c0 = area_off[school_area_begin(s)] - c_lo, c1 = area_off[school_area_begin(s + 1)] - c_lo;
         std::vector<uint32_t> by_age[18], teachers;
         for (uint32_t c = c0; c < c1; ++c) {
             if (occ[c] == OCC_STUDENT) by_age[age[c]].push_back(c);
@@ -196,17 +206,18 @@ extern "C" int esim_synth_create(const esim_synth_spec *spec, esim_population *o
         for (uint32_t attempt = 0; attempt < 64; ++attempt) {
             philox_out o = rng.block(i, attempt, DOM_SEED);
             uint32_t a = (uint32_t)(((uint64_t)o.w0 * A) >> 32);
-            uint32_t n = area_off[a + 1] - area_off[a];
-            if (!n) continue;                                   // empty area: the reference logs and skips
-            seeds.push_back(area_off[a] + (uint32_t)(((uint64_t)o.w1 * n) >> 32));
+            uint32_t na = area_off[a + 1] - area_off[a];
+            if (!na) continue;                                  // empty area: the reference logs and skips
+            const uint32_t g = area_off[a] + (uint32_t)(((uint64_t)o.w1 * na) >> 32);
+            if (g >= c_lo && g < c_hi) seeds.push_back(g - c_lo);
             break;
         }
     }
 
     std::memset(out, 0, sizeof *out);
-    out->n_citizens = N; out->n_buildings = (uint32_t)bld_area.size(); out->n_areas = A;
+    out->n_citizens = n; out->n_buildings = (uint32_t)bld_area.size(); out->n_areas = A;
     out->n_rooms = (uint32_t)room_bld.size(); out->n_seeds = (uint32_t)seeds.size();
-    out->citizen_id_base = 0; out->n_citizens_global = N;
+    out->citizen_id_base = c_lo; out->n_citizens_global = N;
     out->home_building = dup(home); out->work_building = dup(work); out->room = dup(room);
     out->flags = dup(flags); out->age = dup(age); out->occupation = dup(occ);
     out->building_area = dup(bld_area); out->building_type = dup(bld_type);
@@ -218,6 +229,16 @@ extern "C" int esim_synth_create(const esim_synth_spec *spec, esim_population *o
         return ESIM_ENOMEM;
     }
     return ESIM_OK;
+}
+
+extern "C" int esim_synth_create(const esim_synth_spec *spec, esim_population *out)
+{
+    return synth_generate(spec, 0, 1, out);
+}
+
+extern "C" int esim_synth_create_shard(const esim_synth_spec *spec, uint32_t shard, uint32_t n_shards, esim_population *out)
+{
+    return synth_generate(spec, shard, n_shards, out);
 }
 
 extern "C" void esim_synth_free(esim_population *p)

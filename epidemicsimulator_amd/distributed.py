@@ -1,22 +1,65 @@
-"""Output-Area sharded runs: one process per GPU, `torch.distributed` for the two small SUM
-all-reduces a time step needs (backend "nccl" = RCCL over xGMI on the GPU node; "gloo" in tests).
+"""Output-Area sharded runs: one process per GPU, `torch.distributed` for the collectives
+(backend "nccl" = RCCL over xGMI on the GPU node; "gloo" in tests).
 
 The reference has no distributed path (README.md:24 lists it as future work); the sharding follows
 its only data-parallel axis, the Output Areas (sim/src/simulator.rs:167).  Citizens live on the shard
-of their home area; the infected counts of buildings / school rooms whose members live on several
-shards, the census and the vaccination liveness bits travel in the exchange buffers
-(include/esim.h: esim_step_begin / esim_step_exposures / esim_step_finish).
+of their home area.  Two modes (include/esim.h):
+
+* coupled -- every step is split in three device phases around two small SUM all-reduces: A = census +
+  infected counts of buildings / school rooms whose members live on several shards (the commuter
+  exchange), B = exposure totals, eligible count and vaccination-candidate liveness bits.
+* decoupled -- when the shards share no building and no vaccination programme runs, the only thing a
+  shard needs from the others is the global Infected count for the intervention thresholds, and that is
+  known exposed_time + 1 steps ahead (a citizen exposed now is not Infected before).  Shards exchange the
+  vector of their next <= 96 Infected counts once per batch and run the batch without any collective.
+  The host reads the reduced vector, finds the step at which vaccination would trigger, and switches to
+  the coupled mode from that step on.
 """
 import ctypes as C
 
 import numpy as np
 
 from . import _lib
+from .population import Population
 from .simulator import RECORD_DTYPE
+
+_SUMMED = ("susceptible", "exposed", "infected", "recovered", "vaccinated", "exposures_building",
+           "exposures_bus", "n_riders")
+
+
+def clean_cuts(pop, n_shards):
+    """Area boundaries for `n_shards` shards of a whole population: as even in citizens as possible among the
+    boundaries that no citizen commutes across (home area on one side, work building on the other); falls
+    back to the least-crossed boundary near the even split."""
+    ah = pop.building_area[pop.home_building].astype(np.int64)
+    aw = pop.building_area[pop.work_building].astype(np.int64)
+    lo, hi = np.minimum(ah, aw), np.maximum(ah, aw)
+    diff = np.zeros(pop.n_areas + 2, np.int64)
+    m = lo != hi
+    np.add.at(diff, lo[m] + 1, 1)
+    np.add.at(diff, hi[m] + 1, -1)
+    crossings = np.cumsum(diff)[: pop.n_areas + 1]          # crossings[b]: commuters across the boundary before area b
+    per_area = np.bincount(ah, minlength=pop.n_areas)
+    cum = np.concatenate([[0], np.cumsum(per_area)])
+    cuts = [0]
+    for k in range(1, n_shards):
+        target = pop.n_citizens * k / n_shards
+        cand = np.arange(cuts[-1] + 1, pop.n_areas)
+        if cand.size == 0:
+            cuts.append(pop.n_areas)
+            continue
+        cost = crossings[cand] * float(pop.n_citizens) + np.abs(cum[cand] - target)
+        cuts.append(int(cand[np.argmin(cost)]))
+    cuts.append(pop.n_areas)
+    return np.maximum.accumulate(np.asarray(cuts, np.uint32))
 
 
 class ShardedSimulator:
-    def __init__(self, whole_population, rank, world_size, params=None, device_index=0, group=None):
+    """One rank of a sharded run.  Give either `whole_population` (cut here with `cuts`, default
+    clean_cuts) or `shard_population` (already this rank's shard, e.g. Population.synthetic_shard)."""
+
+    def __init__(self, whole_population=None, rank=0, world_size=1, params=None, device_index=0, group=None,
+                 shard_population=None, cuts=None, decoupled=True):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -24,34 +67,46 @@ class ShardedSimulator:
         self.lib = _lib.load()
         self.params = params if params is not None else _lib.default_params()
         self.params.device = device_index
-        self.cuts = whole_population.even_cuts(world_size)
-        self.population = whole_population.shard(self.cuts, rank)
-        self.n_citizens_global = whole_population.n_citizens
+        if shard_population is not None:
+            self.population = shard_population
+        else:
+            self.cuts = clean_cuts(whole_population, world_size) if cuts is None else np.asarray(cuts, np.uint32)
+            self.population = whole_population.shard(self.cuts, rank)
+        self.n_citizens_global = self.population.n_citizens_global
         self._ctx = C.c_void_p()
         torch.cuda.set_device(device_index)
         _lib.check(self.lib.esim_create(C.byref(self.params), C.byref(self._ctx)))
         ps = self.population.as_struct()
-        if world_size == 1:          # a single shard is an ordinary (unsharded) population
-            ps.n_citizens_global = ps.n_citizens
         _lib.check(self.lib.esim_upload_population(self._ctx, C.byref(ps)), self._ctx)
         self.sharded = world_size > 1
         self._steps = 0
+        self._local_ranges = []          # [first, last] step ranges whose records hold this shard's census only
+        self.coupled_steps = 0
+        self.free_steps = 0
+        self.mode_free = bool(decoupled) and self.sharded and self.population.n_shared_buildings == 0 \
+            and self.population.n_shared_rooms == 0
         if self.sharded:
+            # every rank must take the same branch: decoupled only if NO rank shares a building
+            flag = torch.tensor([0 if self.mode_free else 1], dtype=torch.int32, device="cuda:%d" % device_index)
+            dist.all_reduce(flag, group=group)
+            self.mode_free = int(flag.item()) == 0
             # collectives are ordered against this stream; the library enqueues its kernels on it too
             self.stream = torch.cuda.Stream(device=device_index)
             _lib.check(self.lib.esim_set_stream(self._ctx, C.c_void_p(self.stream.cuda_stream)), self._ctx)
             self.xbuf = []
-            for which in (0, 1):
+            for which in (0, 1, 2):
                 n = C.c_size_t(0)
                 ptr = C.c_void_p()
                 _lib.check(self.lib.esim_exchange_buffer(self._ctx, which, C.byref(ptr), C.byref(n)), self._ctx)
-                t = torch.zeros(n.value, dtype=torch.int32, device="cuda:%d" % device_index)
+                t = torch.zeros(max(1, n.value), dtype=torch.int32, device="cuda:%d" % device_index)
                 _lib.check(self.lib.esim_set_exchange_buffer(self._ctx, which, C.c_void_p(t.data_ptr())), self._ctx)
                 self.xbuf.append(t)
+            self.free_batch = int(self.xbuf[2].numel())
             torch.cuda.synchronize()
 
+    # ------------------------------------------------------------------------------------------
     def run(self, n_steps):
-        """n_steps time steps; returns nothing (read the records afterwards) so no host sync is forced."""
+        """n_steps time steps (read the records afterwards)."""
         lib, ctx = self.lib, self._ctx
         if not self.sharded:
             buf = (_lib.StepResult * max(1, n_steps))()
@@ -60,27 +115,75 @@ class ShardedSimulator:
             self._steps += n_steps
             return
         torch, dist = self.torch, self.dist
+        thr = float(self.params.vaccination_threshold)
+        done = 0
         with torch.cuda.stream(self.stream):
-            for _ in range(n_steps):
+            while done < n_steps:
+                if self.mode_free:
+                    _lib.check(lib.esim_future_infected(ctx), ctx)
+                    dist.all_reduce(self.xbuf[2], group=self.group)
+                    future = self.xbuf[2].cpu().numpy().astype(np.int64)      # the one host sync per batch
+                    over = np.nonzero(thr < future / float(self.n_citizens_global))[0]
+                    n_free = int(over[0]) if over.size else self.free_batch
+                    n_free = min(n_free, n_steps - done)
+                    if n_free > 0:
+                        _lib.check(lib.esim_run_free(ctx, n_free), ctx)
+                        self._local_ranges.append((self._steps + 1, self._steps + n_free))
+                        self._steps += n_free
+                        self.free_steps += n_free
+                        done += n_free
+                    if over.size and done < n_steps:
+                        self.mode_free = False        # the programme starts in the next step: coupled from here on
+                    continue
                 _lib.check(lib.esim_step_begin(ctx), ctx)
                 dist.all_reduce(self.xbuf[0], group=self.group)
                 _lib.check(lib.esim_step_exposures(ctx), ctx)
                 dist.all_reduce(self.xbuf[1], group=self.group)
                 _lib.check(lib.esim_step_finish(ctx, None), ctx)
-        self._steps += n_steps
+                self._steps += 1
+                self.coupled_steps += 1
+                done += 1
 
     def synchronize(self):
         _lib.check(self.lib.esim_synchronize(self._ctx), self._ctx)
 
-    def records(self, first_step=1, n=None):
+    def local_records(self, first_step=1, n=None):
         n = self._steps - first_step + 1 if n is None else n
         buf = (_lib.StepResult * max(1, n))()
         _lib.check(self.lib.esim_read_records(self._ctx, first_step, n, buf), self._ctx)
         return np.frombuffer(buf, dtype=RECORD_DTYPE, count=n).copy()
 
-    def reset(self):
+    def records(self, first_step=1, n=None):
+        """Whole-population records: steps run decoupled hold per-shard counts and are summed over the ranks
+        here (one all-reduce for the whole range); coupled steps are already global."""
+        rec = self.local_records(first_step, n)
+        if not self.sharded or not self._local_ranges:
+            return rec
+        torch, dist = self.torch, self.dist
+        steps = rec["time_step"].astype(np.int64)
+        local = np.zeros(len(rec), bool)
+        for a, b in self._local_ranges:
+            local |= (steps >= a) & (steps <= b)
+        vals = np.stack([np.where(local, rec[f], 0).astype(np.int64) for f in _SUMMED])
+        t = torch.from_numpy(vals).to("cuda:%d" % self.params.device)
+        dist.all_reduce(t, group=self.group)
+        tot = t.cpu().numpy()
+        for i, f in enumerate(_SUMMED):
+            rec[f] = np.where(local, tot[i], rec[f]).astype(np.uint32)
+        rec["disease_exists"] = np.where(local, (rec["susceptible"] + rec["exposed"] + rec["infected"]) != 0,
+                                         rec["disease_exists"]).astype(np.uint32)
+        return rec
+
+    def reset(self, decoupled=True):
         _lib.check(self.lib.esim_reset(self._ctx), self._ctx)
         self._steps = 0
+        self._local_ranges = []
+        self.coupled_steps = self.free_steps = 0
+        if self.sharded:
+            free = bool(decoupled) and self.population.n_shared_buildings == 0 and self.population.n_shared_rooms == 0
+            flag = self.torch.tensor([0 if free else 1], dtype=self.torch.int32, device="cuda:%d" % self.params.device)
+            self.dist.all_reduce(flag, group=self.group)
+            self.mode_free = int(flag.item()) == 0
 
     def download_state(self):
         n = self.population.n_citizens

@@ -90,6 +90,24 @@ class Population:
         finally:
             lib.esim_synth_free(C.byref(s))
 
+    @classmethod
+    def synthetic_shard(cls, shard, n_shards, preset=None, **spec_overrides):
+        """Shard `shard` of `n_shards` of the synthetic world, generated directly (esim_synth_create_shard):
+        a run of whole school catchments, so it shares no building with the other shards."""
+        lib = _lib.load()
+        spec = _lib.SynthSpec()
+        _lib.check(lib.esim_synth_preset((preset or "york").encode(), C.byref(spec)))
+        for k, v in spec_overrides.items():
+            if not hasattr(spec, k):
+                raise AttributeError("esim_synth_spec has no field %r" % k)
+            setattr(spec, k, v)
+        s = _lib.PopulationStruct()
+        _lib.check(lib.esim_synth_create_shard(C.byref(spec), shard, n_shards, C.byref(s)))
+        try:
+            return cls._from_struct(s)
+        finally:
+            lib.esim_synth_free(C.byref(s))
+
     def shard(self, cuts, index):
         """The shard of Output Areas [cuts[index], cuts[index+1]) (esim_shard_population)."""
         lib = _lib.load()

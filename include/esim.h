@@ -143,7 +143,18 @@ int  esim_run(esim_ctx *ctx, uint32_t n_steps, int stop_when_done,
 int  esim_step_begin(esim_ctx *ctx);
 int  esim_step_exposures(esim_ctx *ctx);
 int  esim_step_finish(esim_ctx *ctx, esim_step_result *out /* may be NULL */);
-int  esim_exchange_buffer(esim_ctx *ctx, int which /* 0 = A, 1 = B */, void **device_ptr, size_t *n_u32);
+int  esim_exchange_buffer(esim_ctx *ctx, int which /* 0 = A, 1 = B, 2 = F */, void **device_ptr, size_t *n_u32);
+/* Decoupled form for shards that share no building (n_shared_* == 0) while no vaccination programme runs.
+ * A citizen exposed in step t is Infected no earlier than t + exposed_time + 1 (disease.rs:47-71), so after
+ * step t0 every shard already knows its Infected census of steps t0+1 .. t0+n (n = size of buffer F <=
+ * exposed_time + 1), and the interventions (interventions.rs:110-184) need nothing else from other shards:
+ *   esim_future_infected -- writes this shard's Infected census of the next n steps into buffer F
+ *   [SUM all-reduce of F; the caller may read it to find the step at which vaccination would trigger]
+ *   esim_run_free(k)     -- k <= n whole steps without any exchange; records hold THIS shard's census
+ * The caller must return to the coupled steps before the step whose infected fraction exceeds
+ * vaccination_threshold (the device flags ESIM_ESTATE otherwise). */
+int  esim_future_infected(esim_ctx *ctx);
+int  esim_run_free(esim_ctx *ctx, uint32_t n_steps);
 /* Record log read-back for split-phase runs (records first..first+n-1, 1-based time steps). */
 int  esim_read_records(esim_ctx *ctx, uint32_t first_step, uint32_t n, esim_step_result *out);
 /* The HIP stream all work of this context is enqueued on (hipStream_t as void*).  esim_set_stream
@@ -203,6 +214,11 @@ typedef struct esim_synth_spec {
 int  esim_synth_preset(const char *name, esim_synth_spec *out);
 /* Allocates the arrays of *out (shared_* left empty); release with esim_synth_free. */
 int  esim_synth_create(const esim_synth_spec *spec, esim_population *out);
+/* The shard `shard` of `n_shards` of the same world, generated directly (without building the whole):
+ * a run of whole school catchments, so it shares no building with other shards; citizen_id_base and
+ * n_citizens_global are set, Philox counters stay global.  The shards of a spec concatenate to exactly
+ * what esim_synth_create returns for it. */
+int  esim_synth_create_shard(const esim_synth_spec *spec, uint32_t shard, uint32_t n_shards, esim_population *out);
 void esim_synth_free(esim_population *pop);
 /* Cuts the shard of Output Areas [area_begin, area_end) out of a whole population:
  * citizens living there, every building/room they reference (remote ones become ghosts),

@@ -24,8 +24,18 @@ def main():
     dist.init_process_group(cfg["backend"], rank=rank, world_size=world)
     pop = Population.synthetic("york", **cfg["spec"])
     ep = _lib.default_params(**cfg["params"])
-    sim = ShardedSimulator(pop, rank, world, ep, device_index=int(os.environ.get("LOCAL_RANK", "0")))
-    assert sim.population.n_shared_buildings > 0 or world == 1
+    dev = int(os.environ.get("LOCAL_RANK", "0"))
+    if cfg.get("cuts") == "even":              # cuts through school catchments: shared buildings, coupled steps
+        sim = ShardedSimulator(pop, rank, world, ep, device_index=dev, cuts=pop.even_cuts(world))
+        assert sim.population.n_shared_buildings > 0 and not sim.mode_free
+    elif cfg.get("cuts") == "generated":       # each rank generates its own shard directly
+        from epidemicsimulator_amd import Population as P
+        sim = ShardedSimulator(None, rank, world, ep, device_index=dev,
+                               shard_population=P.synthetic_shard(rank, world, "york", **cfg["spec"]))
+        assert sim.mode_free
+    else:                                      # commuter-free cuts: decoupled batches until vaccination starts
+        sim = ShardedSimulator(pop, rank, world, ep, device_index=dev)
+        assert sim.population.n_shared_buildings == 0 and sim.mode_free
     orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
     done = 0
     while done < cfg["steps"]:
@@ -49,8 +59,11 @@ def main():
     dist.barrier()
     sim.close()
     dist.destroy_process_group()
-    print("rank %d ok: %d steps, %d local citizens, %d shared buildings, %d shared rooms"
-          % (rank, cfg["steps"], hi - lo, sim.population.n_shared_buildings, sim.population.n_shared_rooms))
+    if cfg.get("expect_both_modes"):
+        assert sim.free_steps > 0 and sim.coupled_steps > 0, (sim.free_steps, sim.coupled_steps)
+    print("rank %d ok: %d steps (%d decoupled, %d coupled), %d local citizens, %d shared buildings, %d shared rooms"
+          % (rank, cfg["steps"], sim.free_steps, sim.coupled_steps, hi - lo, sim.population.n_shared_buildings,
+             sim.population.n_shared_rooms))
 
 
 if __name__ == "__main__":

@@ -86,6 +86,41 @@ def test_sharding_covers_the_population():
     assert sum(s.n_seeds for s in shards) == pop.n_seeds
 
 
+def test_generated_shards_concatenate_to_the_whole():
+    spec = dict(n_citizens=30000, n_areas=90, citizens_per_school=2500, n_seeds=25)
+    whole = Population.synthetic("york", **spec)
+    shards = [Population.synthetic_shard(i, 4, "york", **spec) for i in range(4)]
+    assert [s.citizen_id_base for s in shards] == list(np.cumsum([0] + [s.n_citizens for s in shards[:-1]]))
+    assert sum(s.n_citizens for s in shards) == whole.n_citizens
+    assert all(s.n_citizens_global == whole.n_citizens and s.n_shared_buildings == 0 for s in shards)
+    assert (np.concatenate([s.flags for s in shards]) == whole.flags).all()
+    assert (np.concatenate([s.age for s in shards]) == whole.age).all()
+    b0, r0 = 0, 0
+    for s in shards:                                  # buildings and rooms are renumbered per shard, in order
+        lo = s.citizen_id_base
+        assert (s.home_building + b0 == whole.home_building[lo:lo + s.n_citizens]).all()
+        assert (s.work_building + b0 == whole.work_building[lo:lo + s.n_citizens]).all()
+        m = s.room != _lib.NO_ROOM
+        assert (s.room[m] + r0 == whole.room[lo:lo + s.n_citizens][m]).all()
+        assert (s.building_area == whole.building_area[b0:b0 + s.n_buildings]).all()
+        assert (s.building_type == whole.building_type[b0:b0 + s.n_buildings]).all()
+        b0 += s.n_buildings
+        r0 += s.n_rooms
+    assert b0 == whole.n_buildings and r0 == whole.n_rooms
+    seeds = sorted(int(x) + s.citizen_id_base for s in shards for x in s.seeds)
+    assert seeds == sorted(whole.seeds.tolist())
+
+
+def test_clean_cuts_avoid_commuters():
+    from epidemicsimulator_amd.distributed import clean_cuts
+    pop = Population.synthetic("york", n_citizens=40000, n_areas=120, citizens_per_school=2500)
+    cuts = clean_cuts(pop, 4)
+    shards = [pop.shard(cuts, i) for i in range(4)]
+    assert all(s.n_shared_buildings == 0 and s.n_shared_rooms == 0 for s in shards)
+    sizes = [s.n_citizens for s in shards]
+    assert max(sizes) < 1.5 * min(sizes)
+
+
 def test_compute_fails_loudly_without_gpu(has_gpu):
     if has_gpu:
         pytest.skip("GPU present")

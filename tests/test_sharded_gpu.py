@@ -47,15 +47,34 @@ AGGRESSIVE = dict(exposure_chance=0.004, vaccination_rate=40, vaccination_thresh
                   mask_pt_threshold=0.005, mask_everywhere_threshold=0.01, seed=77, max_steps=700)
 
 
-def test_two_shards_match_oracle():
-    cfg = dict(backend="gloo", spec=dict(n_citizens=12000, n_areas=40, citizens_per_school=2500, n_seeds=16),
+def test_two_shards_coupled_match_oracle():
+    # cuts through school catchments => shared buildings/rooms => coupled steps with two all-reduces
+    cfg = dict(backend="gloo", cuts="even", spec=dict(n_citizens=12000, n_areas=40, citizens_per_school=2500, n_seeds=16),
                params=AGGRESSIVE, steps=360, chunk=120)
     outs = launch(2, cfg)
     assert all("ok" in o for o in outs)
 
 
-def test_three_uneven_shards_match_oracle():
-    cfg = dict(backend="gloo", spec=dict(n_citizens=9000, n_areas=13, citizens_per_school=3000, n_seeds=16),
+def test_three_uneven_shards_coupled_match_oracle():
+    cfg = dict(backend="gloo", cuts="even", spec=dict(n_citizens=9000, n_areas=13, citizens_per_school=3000, n_seeds=16),
                params=dict(AGGRESSIVE, seed=9), steps=240, chunk=120)
+    outs = launch(3, cfg)
+    assert all("ok" in o for o in outs)
+
+
+def test_two_shards_decoupled_then_coupled_match_oracle():
+    # commuter-free cuts: decoupled 96-step batches (one all-reduce each) until the vaccination trigger,
+    # coupled steps afterwards; records of the decoupled part are summed over the ranks
+    cfg = dict(backend="gloo", cuts="clean", expect_both_modes=True,
+               spec=dict(n_citizens=12000, n_areas=40, citizens_per_school=2500, n_seeds=16),
+               params=AGGRESSIVE, steps=600, chunk=150)
+    outs = launch(2, cfg)
+    assert all("ok" in o for o in outs)
+
+
+def test_three_generated_shards_match_oracle():
+    # every rank generates only its own shard (esim_synth_create_shard); the oracle runs the whole world
+    cfg = dict(backend="gloo", cuts="generated", spec=dict(n_citizens=15000, n_areas=48, citizens_per_school=2500, n_seeds=16),
+               params=dict(AGGRESSIVE, seed=21), steps=500, chunk=250)
     outs = launch(3, cfg)
     assert all("ok" in o for o in outs)
