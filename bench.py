@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--preset", default="uk64m", help="synthetic population preset (default: the benchmark workload)")
     ap.add_argument("--cpu-steps", type=int, default=24, help="time steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--timing-stride", type=int, default=16, help="bracket the per-citizen kernels with HIP events every n-th step")
+    ap.add_argument("--small-limit", type=int, default=None, help="override the persistent-kernel hand-over threshold (Infected citizens)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
@@ -83,6 +84,8 @@ def main():
     pop = Population.synthetic_shard(rank, world, args.preset, n_citizens=n_total, n_areas=n_areas)
     params = _lib.default_params(max_steps=max(steps, warmup, 1))
     sim = ShardedSimulator(None, rank, world, params, device_index=local_rank, shard_population=pop)
+    if args.small_limit is not None:
+        sim.set_small_step_limit(args.small_limit)
 
     def fence():
         sim.synchronize()
@@ -105,15 +108,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kt = sim.kernel_timings()
+    ks = sim.small_kernel_timing()
     rec = sim.records(1, steps)
 
     if rank == 0:
         n_local = sim.population.n_citizens
         value = n_total * steps / elapsed
-        # The three kernels of a time step together carry SURVEY.md 8(d)'s 26 algorithmic bytes per
-        # citizen-timestep, so the roofline is priced on their summed average launch durations.
-        step_ms = kt["k_infected_ms"] + kt["k_expose_ms"] + kt["k_finish_ms"]
-        dom = max(("k_infected", "k_expose", "k_finish"), key=lambda k: kt[k + "_ms"])
+        # One time step = one pass of the hot path.  Steps with few Infected citizens run inside the persistent
+        # single-workgroup kernel k_small (many steps per launch, timed exactly by HIP events around each
+        # launch); the others run as k_infected + k_expose + k_finish (bracketed by HIP events every n-th step).
+        # Together they carry SURVEY.md 8(d)'s 26 algorithmic bytes per citizen-timestep.
+        big_step_ms = kt["k_infected_ms"] + kt["k_expose_ms"] + kt["k_finish_ms"]
+        big_steps = steps - ks["steps"]
+        step_ms = (ks["k_small_ms"] + big_steps * big_step_ms) / steps
+        dom = "k_small" if ks["k_small_ms"] >= big_steps * big_step_ms else \
+            max(("k_infected", "k_expose", "k_finish"), key=lambda k: kt[k + "_ms"])
         algo_bytes = ALGO_BYTES_PER_CITIZEN_STEP * n_local
         achieved = algo_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
         traffic = None
@@ -134,9 +143,13 @@ def main():
                        "decoupled_steps": sim.free_steps, "coupled_steps": sim.coupled_steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_infected+k_expose+k_finish (one time step); longest: " + dom,
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": step_ms, "launches_timed": kt["launches"],
-                         "kernels_ms": {k: kt[k + "_ms"] for k in ("k_infected", "k_expose", "k_finish")},
+                         "kernel": "one time step = k_small (persistent, many steps per launch) or "
+                                   "k_infected+k_expose+k_finish; most time in: " + dom,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": step_ms,
+                         "k_small": {"steps": ks["steps"], "total_ms": ks["k_small_ms"],
+                                     "ms_per_step": ks["k_small_ms"] / ks["steps"] if ks["steps"] else None},
+                         "multi_kernel_steps": {"steps": big_steps, "steps_timed": kt["launches"],
+                                                "kernels_ms": {k: kt[k + "_ms"] for k in ("k_infected", "k_expose", "k_finish")}},
                          "note": "frac > 1 means the kernels touch fewer bytes than the 26 B/citizen-timestep model: only "
                                  "infected citizens and the members of the buildings they stand in are visited (DESIGN.md)",
                          "wall_algorithmic_GBs": ALGO_BYTES_PER_CITIZEN_STEP * n_total * steps / elapsed / 1e9},

@@ -40,6 +40,9 @@ struct esim_ctx_impl {
     std::vector<hipEvent_t> kev;       // six per timed step: k_infected, k_expose, k_finish start/stop
     size_t kev_used = 0;
     uint32_t grid_citizens = 1, grid_infected = 1, grid_expose = 1;
+    uint32_t small_max = 128;          // infected-slice length up to which the persistent single-workgroup kernel runs a step
+    hipEvent_t sev[2] = { nullptr, nullptr };   // k_small timing
+    double small_ms = 0; uint64_t small_steps = 0;
 };
 
 #define CTX(c) (reinterpret_cast<esim_ctx_impl *>(c))
@@ -171,6 +174,7 @@ extern "C" void esim_destroy(esim_ctx *ctx)
     free_device(c);
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->kev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->sev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -374,6 +378,7 @@ extern "C" int esim_reset(esim_ctx *ctx)
     c->host_t = 1;
     c->phase_s[0] = c->phase_s[1] = c->phase_s[2] = 0;
     c->kev_used = 0;
+    c->small_ms = 0; c->small_steps = 0;
     return ESIM_OK;
 }
 
@@ -488,6 +493,47 @@ extern "C" int esim_step_finish(esim_ctx *ctx, esim_step_result *out)
     return ESIM_OK;
 }
 
+extern "C" int esim_step(esim_ctx *ctx, esim_step_result *out);
+
+namespace {
+
+// Runs up to n_steps steps in `mode` (0 one shard, 2 free-running shard).  While few citizens are Infected
+// the persistent single-workgroup kernel advances many steps per launch; when a step's infected slice is
+// longer than small_max it returns and a chunk of steps goes through the multi-workgroup kernels.
+int run_steps(esim_ctx_impl *c, uint32_t n_steps, int mode, bool allow_early_stop, uint32_t *executed)
+{
+    Dev &d = c->d;
+    uint32_t remaining = n_steps, total = 0;
+    int rc;
+    while (remaining > 0) {
+        if (c->small_max > 0 && !c->phase_timing) {
+            if (c->kernel_timing) { if (!c->sev[0]) { (void)hipEventCreate(&c->sev[0]); (void)hipEventCreate(&c->sev[1]); } HIP_TRY(c, hipEventRecord(c->sev[0], c->stream)); }
+            hipLaunchKernelGGL(k_small, dim3(1), dim3(FIN_TPB), 0, c->stream, d, remaining, c->small_max, mode);
+            if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->sev[1], c->stream));
+            Ctrl h;
+            HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->kernel_timing && h.small_done) { float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->sev[0], c->sev[1])); c->small_ms += ms; c->small_steps += h.small_done; }
+            c->host_t += h.small_done; total += h.small_done; remaining -= h.small_done;
+            if (h.error) return fail(c, -(int)h.error, "device-side error (S underflow / vaccination window exhausted / free run past the trigger)");
+            if (h.finished && allow_early_stop) break;
+        }
+        if (remaining == 0) break;
+        const uint32_t chunk = std::min<uint32_t>(remaining, (c->small_max > 0 && !c->phase_timing) ? 32u : remaining);
+        for (uint32_t s = 0; s < chunk; ++s) {
+            const bool tk = want_kernel_timing(c);
+            if ((rc = enqueue_begin(c, tk))) return rc;
+            if ((rc = enqueue_exposures(c, tk))) return rc;
+            if ((rc = enqueue_finish(c, tk, mode))) return rc;
+        }
+        total += chunk; remaining -= chunk;
+    }
+    if (executed) *executed = total;
+    return ESIM_OK;
+}
+
+}  // namespace
+
 extern "C" int esim_step(esim_ctx *ctx, esim_step_result *out)
 {
     esim_ctx_impl *c = CTX(ctx);
@@ -495,11 +541,10 @@ extern "C" int esim_step(esim_ctx *ctx, esim_step_result *out)
     if (rc) return rc;
     if (c->d.n_shards > 1) return fail(c, ESIM_ESTATE, "esim_step: a sharded population needs the split-phase calls and an all-reduce");
     HIP_TRY(c, hipSetDevice(c->P.device));
-    const bool tk = want_kernel_timing(c);
-    if ((rc = enqueue_begin(c, tk))) return rc;
-    if ((rc = enqueue_exposures(c, tk))) return rc;
-    c->timing_this_step = tk;
-    return esim_step_finish(ctx, out);
+    if ((rc = run_steps(c, 1, 0, false, nullptr))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (out) HIP_TRY(c, hipMemcpy(out, &c->d.records[c->host_t - 1], sizeof *out, hipMemcpyDeviceToHost));
+    return device_error(c);
 }
 
 extern "C" int esim_run(esim_ctx *ctx, uint32_t n_steps, int stop_when_done, esim_step_result *out_array, uint32_t *n_done)
@@ -512,17 +557,13 @@ extern "C" int esim_run(esim_ctx *ctx, uint32_t n_steps, int stop_when_done, esi
     const uint32_t first = c->host_t;
     const uint32_t flag = stop_when_done ? 1u : 0u;
     HIP_TRY(c, hipMemcpyAsync(&c->d.ctrl->stop_when_done, &flag, sizeof flag, hipMemcpyHostToDevice, c->stream));
-    for (uint32_t s = 0; s < n_steps; ++s) {
-        const bool tk = want_kernel_timing(c);
-        if ((rc = enqueue_begin(c, tk))) return rc;
-        if ((rc = enqueue_exposures(c, tk))) return rc;
-        if ((rc = enqueue_finish(c, tk))) return rc;
-    }
+    if ((rc = run_steps(c, n_steps, 0, stop_when_done != 0, nullptr))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     Ctrl h;
     HIP_TRY(c, hipMemcpy(&h, c->d.ctrl, sizeof h, hipMemcpyDeviceToHost));
     if (h.error) return fail(c, -(int)h.error, "device-side error (S underflow / vaccination window exhausted)");
     const uint32_t done = h.steps_done >= first ? h.steps_done - first + 1 : 0;
+    c->host_t = first + done;
     if (out_array && done)
         HIP_TRY(c, hipMemcpy(out_array, &c->d.records[first], sizeof(esim_step_result) * done, hipMemcpyDeviceToHost));
     if (n_done) *n_done = done;
@@ -547,19 +588,14 @@ extern "C" int esim_run_free(esim_ctx *ctx, uint32_t n_steps)
     if (n_steps > c->xf_n) return fail(c, ESIM_EINVAL, "esim_run_free: more steps than the future vector covers");
     if (c->d.n_shared_bld || c->d.n_shared_room) return fail(c, ESIM_ESTATE, "esim_run_free: shards that share buildings need the coupled steps");
     HIP_TRY(c, hipSetDevice(c->P.device));
-    for (uint32_t s = 0; s < n_steps; ++s) {
-        const bool tk = want_kernel_timing(c);
-        if (c->phase_timing) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-        if (tk) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 0], c->stream));
-        hipLaunchKernelGGL(k_infected, dim3(c->grid_infected), dim3(TPB), 0, c->stream, c->d);
-        if (tk) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 1], c->stream));
-        if (c->phase_timing) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-        if (tk) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 2], c->stream));
-        hipLaunchKernelGGL(k_expose, dim3(c->grid_expose), dim3(TPB), 0, c->stream, c->d);
-        if (tk) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 3], c->stream));
-        if (c->phase_timing) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
-        if ((rc = enqueue_finish(c, tk, 2))) return rc;
-    }
+    return run_steps(c, n_steps, 2, false, nullptr);
+}
+
+extern "C" int esim_set_small_step_limit(esim_ctx *ctx, uint32_t max_infected)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c) return ESIM_EINVAL;
+    c->small_max = max_infected;
     return ESIM_OK;
 }
 
@@ -673,6 +709,16 @@ extern "C" int esim_enable_kernel_timing(esim_ctx *ctx, int enable)
     c->kernel_timing = enable > 0;
     if (enable > 0) c->kernel_timing_stride = (uint32_t)enable;   // time every `enable`-th step
     c->kev_used = 0;
+    return ESIM_OK;
+}
+
+extern "C" int esim_small_kernel_timing(esim_ctx *ctx, double *total_ms, uint64_t *steps)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c) return ESIM_EINVAL;
+    if (total_ms) *total_ms = c->small_ms;
+    if (steps) *steps = c->small_steps;
+    c->small_ms = 0; c->small_steps = 0;
     return ESIM_OK;
 }
 

@@ -56,7 +56,8 @@ struct Ctrl {
     uint32_t counts[5];         // census of the step in flight (global when sharded, after unpack)
     uint32_t n_riders;
     uint32_t free_base;         // first step of the current free-running batch (decoupled sharded mode)
-    uint32_t pad[2];
+    uint32_t small_done;        // steps executed by the last k_small launch
+    uint32_t pad[1];
 };
 
 struct Dev {

@@ -33,6 +33,13 @@ __device__ __forceinline__ uint32_t status_of(uint32_t te, uint32_t t, uint32_t 
     return ESIM_RECOVERED;
 }
 
+// Counters that other waves bump with atomics are read past the L1 (they may have been cached by an
+// earlier step of the persistent kernel).
+__device__ __forceinline__ uint32_t ld(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Citizen::execute_time_step's schedule (citizen.rs:176-206) for the whole population at once.
 // The four hours are distinct (checked in esim_create), so every citizen takes the same arm
 // up to the `uses_public_transport` guard, which only decides who is on the bus.
@@ -61,14 +68,14 @@ __device__ void census_block(const Dev &d, const Ctrl *ctrl, uint32_t t, uint32_
     uint32_t e = 0, i = 0;
     for (int k = lo_i + (int)threadIdx.x; k <= hi_e; k += (int)blockDim.x) {
         if (k < 0) continue;
-        const uint32_t v = d.hist[k];
+        const uint32_t v = ld(&d.hist[k]);
         if (k >= lo_e) e += v; else i += v;
     }
     if (e) atomicAdd(&out[1], e);
     if (i) atomicAdd(&out[2], i);
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[0] = ctrl->n_susceptible; out[4] = ctrl->n_vaccinated;
+        out[0] = ld(&ctrl->n_susceptible); out[4] = ld(&ctrl->n_vaccinated);
         out[3] = d.n - out[0] - out[4] - out[1] - out[2];
     }
     __syncthreads();
@@ -83,10 +90,8 @@ __device__ __forceinline__ void append(uint32_t *list, uint32_t *len, uint32_t v
 // The Infected citizens of step t are the log slice with exposure step in
 // [t - exposed_time - 1 - infected_time, t - exposed_time - 1].  simulator.rs:181-198: a rider
 // joins its route's session, anybody else marks current_building_position.
-__global__ __launch_bounds__(TPB) void k_infected(Dev d)
+__device__ __forceinline__ void infected_phase(const Dev &d, Ctrl *ctrl, uint32_t vb, uint32_t nvb)
 {
-    Ctrl *ctrl = d.ctrl;
-    if (ctrl->finished) return;
     const uint32_t t = ctrl->t;
     uint32_t at_work, bus_dir;
     schedule(d, ctrl, t, at_work, bus_dir);
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(TPB) void k_infected(Dev d)
     const int lo = hi - (int)d.infected_time;
     if (hi < 0) return;
     const uint32_t i0 = d.log_off[lo < 0 ? 0 : lo], i1 = d.log_off[hi + 1];
-    for (uint32_t i = i0 + blockIdx.x * TPB + threadIdx.x; i < i1; i += gridDim.x * TPB) {
+    for (uint32_t i = i0 + vb * blockDim.x + threadIdx.x; i < i1; i += nvb * blockDim.x) {
         const uint32_t c = d.log[i];
         if (status_of(d.state[c] & ST_TE_MASK, t, d.exposed_time, d.infected_time) != ESIM_INFECTED) continue;  // vaccinated since (Q10)
         const uint32_t fl = d.flags[c];
@@ -114,6 +119,12 @@ __global__ __launch_bounds__(TPB) void k_infected(Dev d)
             }
         }
     }
+}
+
+__global__ __launch_bounds__(TPB) void k_infected(Dev d)
+{
+    if (d.ctrl->finished) return;
+    infected_phase(d, d.ctrl, blockIdx.x, gridDim.x);
 }
 
 // Threshold for Citizen::expose (citizen.rs:221-248): row 1 of the LUT is p - p*mask_effectiveness,
@@ -214,16 +225,14 @@ __device__ __forceinline__ void bus_draw(const Dev &d, Ctrl *ctrl, uint32_t c, u
 // apply_exposures.  Work items: marked buildings (residents + workers), marked school rooms,
 // marked routes of <= 64 riders -- one wavefront each, lanes over the members; then marked
 // routes of > 64 riders, one workgroup each.
-__global__ __launch_bounds__(TPB) void k_expose(Dev d)
+__device__ __forceinline__ void expose_phase(const Dev &d, Ctrl *ctrl, uint32_t vb, uint32_t nvb)
 {
-    Ctrl *ctrl = d.ctrl;
-    if (ctrl->finished) return;
     const uint32_t t = ctrl->t, mask = ctrl->mask;
     uint32_t at_work, bus_dir;
     schedule(d, ctrl, t, at_work, bus_dir);
-    const uint32_t nb = ctrl->n_touched_bld, nr = ctrl->n_touched_room, nrt = ctrl->n_touched_route;
+    const uint32_t nb = ld(&ctrl->n_touched_bld), nr = ld(&ctrl->n_touched_room), nrt = ld(&ctrl->n_touched_route);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    const uint32_t wave = (vb * blockDim.x + threadIdx.x) >> 6, n_waves = (nvb * blockDim.x) >> 6;
     uint32_t n_exp = 0;
     for (uint32_t it = wave; it < nb + nr + nrt; it += n_waves) {
         if (it < nb) {
@@ -270,11 +279,11 @@ __global__ __launch_bounds__(TPB) void k_expose(Dev d)
         }
     }
     // routes of > 64 riders (rare: a very large Output Area): rank by counting through global scratch
-    const uint32_t nbig = ctrl->n_touched_route_big;
-    for (uint32_t ri = blockIdx.x; ri < nbig; ri += gridDim.x) {
+    const uint32_t nbig = ld(&ctrl->n_touched_route_big);
+    for (uint32_t ri = vb; ri < nbig; ri += nvb) {
         const uint32_t r = d.touched_route_big[ri];
         const uint32_t off = d.route_off[r], s = d.route_off[r + 1] - off;
-        for (uint32_t i = threadIdx.x; i < s; i += TPB) {
+        for (uint32_t i = threadIdx.x; i < s; i += blockDim.x) {
             const uint32_t c = d.route_riders[off + i];
             const bool inf = status_of(d.state[c] & ST_TE_MASK, t, d.exposed_time, d.infected_time) == ESIM_INFECTED;
             d.bus_key[off + i] = philox4x32_10(d.id_base + c, t, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(TPB) void k_expose(Dev d)
             d.bus_cnt[off + i] = 0u;
         }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < s; i += TPB) {
+        for (uint32_t i = threadIdx.x; i < s; i += blockDim.x) {
             const uint32_t key = d.bus_key[off + i];
             uint32_t rank = 0;
             for (uint32_t j = 0; j < s; ++j) {
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(TPB) void k_expose(Dev d)
             if (d.bus_flag[off + i]) atomicAdd(&d.bus_cnt[off + bus], 1u);
         }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < s; i += TPB) {
+        for (uint32_t i = threadIdx.x; i < s; i += blockDim.x) {
             const uint32_t c = d.route_riders[off + i];
             const uint32_t k = __hip_atomic_load(&d.bus_cnt[off + d.bus_idx[off + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (k && (d.state[c] & ST_TE_MASK) == TE_SUSCEPTIBLE) bus_draw(d, ctrl, c, k, t, mask, at_work);
@@ -302,6 +311,12 @@ __global__ __launch_bounds__(TPB) void k_expose(Dev d)
         __syncthreads();
     }
     if (n_exp) atomicAdd(&ctrl->exp_bld, n_exp);
+}
+
+__global__ __launch_bounds__(TPB) void k_expose(Dev d)
+{
+    if (d.ctrl->finished) return;
+    expose_phase(d, d.ctrl, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------- exchange
@@ -419,15 +434,22 @@ __device__ __forceinline__ void vaccinate(const Dev &d, Ctrl *ctrl, uint32_t c)
 // (interventions.rs:110-184), the vaccination draw (simulator.rs:524-553), the StatisticEntry of the
 // step (statistics.rs:208-215, adjusted by citizen_exposed :275-287), and the hand-over to step t+1.
 #define FIN_TPB 1024
-__global__ __launch_bounds__(FIN_TPB) void k_finish(Dev d, int sharded)
+struct FinishShared {
+    uint32_t tab_key[VACC_TABLE];
+    uint32_t tab_idx[VACC_TABLE];
+    uint32_t wsum[FIN_TPB / 64];
+    uint32_t s_total;
+    uint32_t cen[5];
+};
+
+// Called by one whole workgroup of FIN_TPB threads.
+__device__ __forceinline__ void finish_phase(const Dev &d, Ctrl *ctrl, int sharded, FinishShared &sm)
 {
-    __shared__ uint32_t tab_key[VACC_TABLE];
-    __shared__ uint32_t tab_idx[VACC_TABLE];
-    __shared__ uint32_t wsum[FIN_TPB / 64];
-    __shared__ uint32_t s_total;
-    __shared__ uint32_t cen[5];
-    Ctrl *ctrl = d.ctrl;
-    if (ctrl->finished) return;
+    uint32_t (&tab_key)[VACC_TABLE] = sm.tab_key;
+    uint32_t (&tab_idx)[VACC_TABLE] = sm.tab_idx;
+    uint32_t (&wsum)[FIN_TPB / 64] = sm.wsum;
+    uint32_t &s_total = sm.s_total;
+    uint32_t (&cen)[5] = sm.cen;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t t = ctrl->t;
     uint32_t at_work, bus_dir;
@@ -450,18 +472,19 @@ __global__ __launch_bounds__(FIN_TPB) void k_finish(Dev d, int sharded)
     const bool have = ctrl->have_elig || trig;
     const uint32_t tstep = trig ? t : ctrl->trigger_step;
     // totals over all shards come from exchange buffer B when sharded, the ctrl fields stay per-shard
-    const uint32_t exp_bld = sharded ? d.xb[0] : ctrl->exp_bld;
-    const uint32_t exp_bus = sharded ? d.xb[1] : ctrl->exp_bus;
-    const uint32_t local_elig = trig ? ctrl->n_susceptible - ctrl->exp_bld - ctrl->exp_bus : ctrl->elig_count;
+    const uint32_t my_exp_bld = ld(&ctrl->exp_bld), my_exp_bus = ld(&ctrl->exp_bus);
+    const uint32_t exp_bld = sharded ? d.xb[0] : my_exp_bld;
+    const uint32_t exp_bus = sharded ? d.xb[1] : my_exp_bus;
+    const uint32_t local_elig = trig ? ld(&ctrl->n_susceptible) - my_exp_bld - my_exp_bus : ld(&ctrl->elig_count);
     const uint32_t elig_count = sharded ? d.xb[2] : local_elig;
     const uint32_t n_riders = sharded ? ctrl->n_riders : (bus_dir ? d.n_pt : 0u);
     __syncthreads();
     // this step's exposures enter the books before anybody is vaccinated
     if (tid == 0) {
-        const uint32_t mine = ctrl->exp_bld + ctrl->exp_bus;
-        ctrl->n_susceptible -= mine;
-        d.hist[t + TE_BIAS] += mine;
-        d.log_off[t + TE_BIAS + 1u] = ctrl->log_len;
+        const uint32_t mine = my_exp_bld + my_exp_bus;
+        atomicSub(&ctrl->n_susceptible, mine);
+        atomicAdd(&d.hist[t + TE_BIAS], mine);
+        d.log_off[t + TE_BIAS + 1u] = ld(&ctrl->log_len);
         if (trig) ctrl->elig_count = local_elig;
     }
     __syncthreads();
@@ -534,7 +557,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_finish(Dev d, int sharded)
         }
     }
     // forget this step's marks
-    const uint32_t nb = ctrl->n_touched_bld, nr = ctrl->n_touched_room, nrt = ctrl->n_touched_route, nrb = ctrl->n_touched_route_big;
+    const uint32_t nb = ld(&ctrl->n_touched_bld), nr = ld(&ctrl->n_touched_room), nrt = ld(&ctrl->n_touched_route), nrb = ld(&ctrl->n_touched_route_big);
     for (uint32_t i = tid; i < nb; i += FIN_TPB) d.cnt_bld[d.touched_bld[i]] = 0u;
     for (uint32_t i = tid; i < nr; i += FIN_TPB) d.cnt_room[d.touched_room[i]] = 0u;
     for (uint32_t i = tid; i < nrt; i += FIN_TPB) d.route_flag[d.touched_route[i]] = 0u;
@@ -572,6 +595,49 @@ __global__ __launch_bounds__(FIN_TPB) void k_finish(Dev d, int sharded)
         for (int i = 0; i < 5; ++i) ctrl->counts[i] = 0u;
         ctrl->t = t + 1u;
     }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(FIN_TPB) void k_finish(Dev d, int sharded)
+{
+    __shared__ FinishShared sm;
+    if (d.ctrl->finished) return;
+    finish_phase(d, d.ctrl, sharded, sm);
+}
+
+// ------------------------------------------------------------------------------------- k_small
+// While few citizens are Infected, a whole time step is a handful of dependent memory round trips and
+// three kernel boundaries cost more than the work.  This persistent single-workgroup kernel runs the
+// same three phases back to back (workgroup barriers instead of kernel boundaries) for up to `max_steps`
+// steps, and returns as soon as a step's infected slice exceeds `small_max` (the multi-workgroup kernels
+// take over), the run is finished, or the budget is used.  ctrl->small_done = steps it executed.
+__global__ __launch_bounds__(FIN_TPB) void k_small(Dev d, uint32_t max_steps, uint32_t small_max, int mode)
+{
+    __shared__ FinishShared sm;
+    __shared__ Ctrl sc;                                   // the control block lives in LDS for the whole launch
+    __shared__ uint32_t go;
+    if (threadIdx.x == 0) sc = *d.ctrl;
+    __syncthreads();
+    Ctrl *ctrl = &sc;
+    uint32_t done = 0;
+    for (; done < max_steps; ++done) {
+        if (threadIdx.x == 0) {
+            const uint32_t t = ctrl->t;
+            const int hi = (int)(t + TE_BIAS) - (int)d.exposed_time - 1;
+            const int lo = hi - (int)d.infected_time;
+            const uint32_t len = d.log_off[hi + 1] - d.log_off[lo < 0 ? 0 : lo];
+            go = (!ctrl->finished && !ctrl->error && len <= small_max && t <= d.max_steps) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!go) break;                                   // block-uniform: every wave leaves together
+        infected_phase(d, ctrl, 0u, 1u);
+        __syncthreads();
+        expose_phase(d, ctrl, 0u, 1u);
+        __syncthreads();
+        finish_phase(d, ctrl, mode, sm);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { sc.small_done = done; *d.ctrl = sc; }
 }
 
 // Reference-shaped view of the state (esim_download_state).

@@ -206,6 +206,14 @@ class ShardedSimulator:
         _lib.check(self.lib.esim_kernel_timings(self._ctx, ms, C.byref(n)), self._ctx)
         return {"k_infected_ms": ms[0], "k_expose_ms": ms[1], "k_finish_ms": ms[2], "launches": n.value}
 
+    def set_small_step_limit(self, max_infected):
+        _lib.check(self.lib.esim_set_small_step_limit(self._ctx, int(max_infected)), self._ctx)
+
+    def small_kernel_timing(self):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        _lib.check(self.lib.esim_small_kernel_timing(self._ctx, C.byref(ms), C.byref(n)), self._ctx)
+        return {"k_small_ms": ms.value, "steps": n.value}
+
     def close(self):
         if self._ctx:
             self.lib.esim_destroy(self._ctx)

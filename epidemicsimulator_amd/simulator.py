@@ -142,6 +142,16 @@ class Simulator:
         _lib.check(self.lib.esim_kernel_timings(self._ctx, ms, C.byref(n)), self._ctx)
         return {"k_infected_ms": ms[0], "k_expose_ms": ms[1], "k_finish_ms": ms[2], "launches": n.value}
 
+    def set_small_step_limit(self, max_infected):
+        """Steps with at most this many Infected citizens run in the persistent single-workgroup kernel
+        (0 = always use the multi-workgroup kernels)."""
+        _lib.check(self.lib.esim_set_small_step_limit(self._ctx, int(max_infected)), self._ctx)
+
+    def small_kernel_timing(self):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        _lib.check(self.lib.esim_small_kernel_timing(self._ctx, C.byref(ms), C.byref(n)), self._ctx)
+        return {"k_small_ms": ms.value, "steps": n.value}
+
     def enable_phase_timing(self, on=True):
         _lib.check(self.lib.esim_enable_phase_timing(self._ctx, int(on)), self._ctx)
 

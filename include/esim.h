@@ -193,6 +193,14 @@ int  esim_phase_timings(esim_ctx *ctx, double out[4]);
 int  esim_enable_kernel_timing(esim_ctx *ctx, int enable);
 int  esim_kernel_timings(esim_ctx *ctx, double out_ms[3], uint32_t *out_n);
 
+/* While few citizens are Infected a time step is a handful of dependent memory round trips; a persistent
+ * single-workgroup kernel then advances many steps per launch (workgroup barriers instead of kernel
+ * boundaries).  It hands over to the multi-workgroup kernels whenever a step has more than `max_infected`
+ * Infected citizens (default 128; 0 disables it).  esim_small_kernel_timing: accumulated duration (ms) and
+ * steps of those launches while kernel timing is enabled, then resets the accumulators. */
+int  esim_set_small_step_limit(esim_ctx *ctx, uint32_t max_infected);
+int  esim_small_kernel_timing(esim_ctx *ctx, double *total_ms, uint64_t *steps);
+
 const char *esim_last_error(const esim_ctx *ctx);   /* ctx may be NULL: last esim_create error */
 void esim_destroy(esim_ctx *ctx);
 

@@ -27,9 +27,21 @@ def assert_same_state(sim, orc):
         assert (g[k] == o[k]).all(), k
 
 
-def run_both(pop, steps, check_state_every=None, **params):
+# every scenario runs three ways: default hand-over between the persistent single-workgroup kernel and the
+# multi-workgroup kernels, multi-workgroup kernels only, persistent kernel only
+SMALL_LIMITS = (None, 0, 1 << 30)
+
+
+def run_both(pop, steps, check_state_every=None, small_limits=SMALL_LIMITS, **params):
+    for lim in small_limits:
+        _run_both(pop, steps, check_state_every, lim, **params)
+
+
+def _run_both(pop, steps, check_state_every, small_limit, **params):
     ep = _lib.default_params(**params)
     sim = Simulator(pop, ep)
+    if small_limit is not None:
+        sim.set_small_step_limit(small_limit)
     orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
     if check_state_every:
         done = 0
@@ -82,12 +94,12 @@ def test_step_by_step_equals_run():
 
 
 def test_york_default_params_1000_steps():
-    run_both(Population.synthetic("york"), 1000)
+    run_both(Population.synthetic("york"), 1000, small_limits=(None, 0))
 
 
 def test_york_full_5000_steps_vaccination_85():
     # BASELINE.json configs[1]: York, 5000 steps, fixed Philox seed vs CPU counts; v1.7.1's rate 85/step
-    run_both(Population.synthetic("york"), 5000, vaccination_rate=85, vaccination_threshold=0.003)
+    run_both(Population.synthetic("york"), 5000, small_limits=(None,), vaccination_rate=85, vaccination_threshold=0.003)
 
 
 def test_big_routes_and_u8_truncation():
