@@ -26,6 +26,7 @@ struct esim_ctx_impl {
     std::vector<uint16_t> init_state;
     std::vector<uint32_t> init_log;       // distinct seeds
     size_t cnt_bytes = 0;
+    uint32_t *cnt_base = nullptr;
     uint32_t n_routes = 0;
     size_t xa_n = 0, xb_n = 0, xf_n = 0;
     uint32_t host_t = 1;          // next time step to enqueue
@@ -37,7 +38,7 @@ struct esim_ctx_impl {
     bool timing_this_step = false;
     hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
     double phase_s[3] = { 0, 0, 0 };
-    std::vector<hipEvent_t> kev;       // six per timed step: k_infected, k_expose, k_finish start/stop
+    std::vector<hipEvent_t> kev;       // two per timed step: before k_infected, after k_finish
     size_t kev_used = 0;
     uint32_t grid_citizens = 1, grid_infected = 1, grid_expose = 1;
     uint32_t small_max = 128;          // infected-slice length up to which the persistent single-workgroup kernel runs a step
@@ -297,13 +298,18 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     if ((rc = dev_upload(c, &d.room_bld, pop->room_building, R))) return rc;
     if ((rc = dev_upload(c, &d.bld_type, pop->building_type, B))) return rc;
     uint32_t *cnt = nullptr;
-    if ((rc = dev_alloc(c, &cnt, (size_t)B + R + n_routes))) return rc;
-    d.cnt_bld = cnt; d.cnt_room = cnt + B; d.route_flag = cnt + B + R;
-    c->cnt_bytes = sizeof(uint32_t) * ((size_t)B + R + n_routes);
-    if ((rc = dev_alloc(c, &d.touched_bld, B))) return rc;
-    if ((rc = dev_alloc(c, &d.touched_room, R))) return rc;
-    if ((rc = dev_alloc(c, &d.touched_route, n_routes))) return rc;
-    if ((rc = dev_alloc(c, &d.touched_route_big, n_routes))) return rc;
+    const size_t per_parity = (size_t)B + R + n_routes;
+    if ((rc = dev_alloc(c, &cnt, 2 * per_parity))) return rc;
+    c->cnt_base = cnt;
+    c->cnt_bytes = sizeof(uint32_t) * 2 * per_parity;
+    for (int p = 0; p < 2; ++p) {
+        uint32_t *base = cnt + p * per_parity;
+        d.cnt_bld[p] = base; d.cnt_room[p] = base + B; d.route_flag[p] = base + B + R;
+        if ((rc = dev_alloc(c, &d.touched_bld[p], B))) return rc;
+        if ((rc = dev_alloc(c, &d.touched_room[p], R))) return rc;
+        if ((rc = dev_alloc(c, &d.touched_route[p], n_routes))) return rc;
+        if ((rc = dev_alloc(c, &d.touched_route_big[p], n_routes))) return rc;
+    }
     if ((rc = dev_alloc(c, &d.hist, TE_SLOTS))) return rc;
     if ((rc = dev_alloc(c, &d.log, (size_t)N + 1))) return rc;
     if ((rc = dev_alloc(c, &d.log_off, TE_SLOTS + 1))) return rc;
@@ -342,7 +348,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     HIP_TRY(c, hipMemset(d.xb, 0, sizeof(uint32_t) * c->xb_n));
 
     c->grid_citizens = grid_for(N, TPB, 2048);
-    c->grid_infected = 256;
+    c->grid_infected = 1024;
     c->grid_expose = 1024;
     c->uploaded = true;
     return esim_reset(ctx);
@@ -364,7 +370,7 @@ extern "C" int esim_reset(esim_ctx *ctx)
     h.log_len = n_seeds;
     HIP_TRY(c, hipMemcpy(d.ctrl, &h, sizeof h, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(d.state, c->init_state.data(), sizeof(uint16_t) * ((size_t)d.n + 2), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemset(d.cnt_bld, 0, c->cnt_bytes));
+    HIP_TRY(c, hipMemset(c->cnt_base, 0, c->cnt_bytes));
     HIP_TRY(c, hipMemset(d.records, 0, sizeof(esim_step_result) * ((size_t)c->P.max_steps + 1)));
     // census histogram and exposure log: the seeds are Infected(0) before step 1, i.e. "exposed" at
     // step -(exposed_time + 1)
@@ -390,7 +396,6 @@ int enqueue_begin(esim_ctx_impl *c, bool time_kernel)
     if (c->phase_timing) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     if (time_kernel) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 0], c->stream));
     hipLaunchKernelGGL(k_infected, dim3(c->grid_infected), dim3(TPB), 0, c->stream, d);
-    if (time_kernel) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 1], c->stream));
     if (d.n_shards > 1) {
         const uint32_t n = (uint32_t)std::max<size_t>(XA_HEADER, std::max(d.n_shared_bld, d.n_shared_room));
         hipLaunchKernelGGL(k_pack_a, dim3(grid_for(n, TPB, 1u << 20)), dim3(TPB), 0, c->stream, d);
@@ -406,9 +411,8 @@ int enqueue_exposures(esim_ctx_impl *c, bool time_kernel)
         const uint32_t n = (uint32_t)std::max<size_t>(XA_HEADER, std::max(d.n_shared_bld, d.n_shared_room));
         hipLaunchKernelGGL(k_unpack_a, dim3(grid_for(n, TPB, 1u << 20)), dim3(TPB), 0, c->stream, d);
     }
-    if (time_kernel) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 2], c->stream));
+    (void)time_kernel;
     hipLaunchKernelGGL(k_expose, dim3(c->grid_expose), dim3(TPB), 0, c->stream, d);
-    if (time_kernel) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 3], c->stream));
     if (d.n_shards > 1) hipLaunchKernelGGL(k_pack_b, dim3(VACC_BATCH / TPB), dim3(TPB), 0, c->stream, d);
     if (c->phase_timing) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     return ESIM_OK;
@@ -418,9 +422,8 @@ int enqueue_finish(esim_ctx_impl *c, bool time_kernel, int mode = -1)
 {
     Dev &d = c->d;
     if (mode < 0) mode = d.n_shards > 1 ? 1 : 0;
-    if (time_kernel) HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 4], c->stream));
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(FIN_TPB), 0, c->stream, d, mode);
-    if (time_kernel) { HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 5], c->stream)); c->kev_used += 6; }
+    if (time_kernel) { HIP_TRY(c, hipEventRecord(c->kev[c->kev_used + 1], c->stream)); c->kev_used += 2; }
     if (c->phase_timing) {
         HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
         HIP_TRY(c, hipEventSynchronize(c->ev[3]));
@@ -443,8 +446,8 @@ int check_budget(esim_ctx_impl *c, uint32_t n_steps)
 bool want_kernel_timing(esim_ctx_impl *c)
 {
     if (!c->kernel_timing || (c->host_t % c->kernel_timing_stride) != 0) return false;
-    if (c->kev_used + 6 > c->kev.size()) {
-        for (int i = 0; i < 6; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return false; c->kev.push_back(e); }
+    if (c->kev_used + 2 > c->kev.size()) {
+        for (int i = 0; i < 2; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return false; c->kev.push_back(e); }
     }
     return true;
 }
@@ -722,21 +725,20 @@ extern "C" int esim_small_kernel_timing(esim_ctx *ctx, double *total_ms, uint64_
     return ESIM_OK;
 }
 
-extern "C" int esim_kernel_timings(esim_ctx *ctx, double out_ms[3], uint32_t *out_n)
+extern "C" int esim_kernel_timings(esim_ctx *ctx, double *step_ms, uint32_t *out_n)
 {
     esim_ctx_impl *c = CTX(ctx);
-    if (!c || !out_ms) return ESIM_EINVAL;
+    if (!c || !step_ms) return ESIM_EINVAL;
     HIP_TRY(c, hipSetDevice(c->P.device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    double acc[3] = { 0, 0, 0 };
-    const size_t n = c->kev_used / 6;
-    for (size_t i = 0; i < n; ++i)
-        for (int k = 0; k < 3; ++k) {
-            float ms;
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[6 * i + 2 * k], c->kev[6 * i + 2 * k + 1]));
-            acc[k] += ms;
-        }
-    for (int k = 0; k < 3; ++k) out_ms[k] = n ? acc[k] / n : 0.0;
+    double acc = 0;
+    const size_t n = c->kev_used / 2;
+    for (size_t i = 0; i < n; ++i) {
+        float ms;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->kev[2 * i], c->kev[2 * i + 1]));
+        acc += ms;
+    }
+    *step_ms = n ? acc / n : 0.0;
     if (out_n) *out_n = (uint32_t)n;
     c->kev_used = 0;
     return ESIM_OK;

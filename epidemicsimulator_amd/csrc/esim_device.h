@@ -51,13 +51,14 @@ struct Ctrl {
     uint32_t n_susceptible, n_vaccinated, n_recovered_sentinel;
     uint32_t log_len;           // entries in the exposure log
     // per-step work lists (zeroed by k_finish)
-    uint32_t n_touched_bld, n_touched_room, n_touched_route, n_touched_route_big;
+    // (double-buffered by step parity: the marks of step t are cleared by the multi-workgroup k_expose of step t+1)
+    uint32_t n_touched_bld[2], n_touched_room[2], n_touched_route[2], n_touched_route_big[2];
     uint32_t exp_bld, exp_bus;
     uint32_t counts[5];         // census of the step in flight (global when sharded, after unpack)
     uint32_t n_riders;
     uint32_t free_base;         // first step of the current free-running batch (decoupled sharded mode)
     uint32_t small_done;        // steps executed by the last k_small launch
-    uint32_t pad[1];
+    uint32_t pad[5];
 };
 
 struct Dev {
@@ -75,10 +76,11 @@ struct Dev {
     const uint32_t *room_off, *room_idx;    // participants per school room
     const uint32_t *room_bld;               // [n_room] school of each room
     const uint8_t  *bld_type;
-    uint32_t *cnt_bld;          // [n_bld] infected citizens standing in each building this step
-    uint32_t *cnt_room;         // [n_room] ... in each school room
-    uint32_t *touched_bld, *touched_room, *touched_route, *touched_route_big;
-    uint32_t *route_flag;       // [n_routes]
+    // marks of a step, one set per step parity p = t & 1
+    uint32_t *cnt_bld[2];       // [n_bld] infected citizens standing in each building this step
+    uint32_t *cnt_room[2];      // [n_room] ... in each school room
+    uint32_t *touched_bld[2], *touched_room[2], *touched_route[2], *touched_route_big[2];
+    uint32_t *route_flag[2];    // [n_routes]
     uint32_t *hist;             // [TE_SLOTS] citizens per exposure time (census without a pass over citizens)
     uint32_t *log;              // exposure log: citizen ids in order of exposure step
     uint32_t *log_off;          // [TE_SLOTS + 1] first log entry whose te >= k

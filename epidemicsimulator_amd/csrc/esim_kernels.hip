@@ -98,6 +98,8 @@ __device__ __forceinline__ void infected_phase(const Dev &d, Ctrl *ctrl, uint32_
     const int hi = (int)(t + TE_BIAS) - (int)d.exposed_time - 1;
     const int lo = hi - (int)d.infected_time;
     if (hi < 0) return;
+    const uint32_t p = t & 1u;
+    uint32_t *cnt_bld = d.cnt_bld[p], *cnt_room = d.cnt_room[p], *route_flag = d.route_flag[p];
     const uint32_t i0 = d.log_off[lo < 0 ? 0 : lo], i1 = d.log_off[hi + 1];
     for (uint32_t i = i0 + vb * blockDim.x + threadIdx.x; i < i1; i += nvb * blockDim.x) {
         const uint32_t c = d.log[i];
@@ -105,17 +107,17 @@ __device__ __forceinline__ void infected_phase(const Dev &d, Ctrl *ctrl, uint32_
         const uint32_t fl = d.flags[c];
         if (bus_dir && (fl & FL_USES_PT)) {                                  // simulator.rs:181-186
             const uint32_t r = d.route_of[c];
-            if (atomicExch(&d.route_flag[r], 1u) == 0u) {
-                if (d.route_off[r + 1] - d.route_off[r] <= 64u) append(d.touched_route, &ctrl->n_touched_route, r);
-                else append(d.touched_route_big, &ctrl->n_touched_route_big, r);
+            if (atomicExch(&route_flag[r], 1u) == 0u) {
+                if (d.route_off[r + 1] - d.route_off[r] <= 64u) append(d.touched_route[p], &ctrl->n_touched_route[p], r);
+                else append(d.touched_route_big[p], &ctrl->n_touched_route_big[p], r);
             }
         } else {                                                             // :187-198
             const bool atw = at_work && (fl & FL_HAS_WORK);
             const uint32_t b = atw ? d.work[c] : d.home[c];
-            if (atomicAdd(&d.cnt_bld[b], 1u) == 0u) append(d.touched_bld, &ctrl->n_touched_bld, b);
+            if (atomicAdd(&cnt_bld[b], 1u) == 0u) append(d.touched_bld[p], &ctrl->n_touched_bld[p], b);
             if (atw && (fl & FL_WORK_SCHOOL)) {
                 const uint32_t r = d.room[c];
-                if (atomicAdd(&d.cnt_room[r], 1u) == 0u) append(d.touched_room, &ctrl->n_touched_room, r);
+                if (atomicAdd(&cnt_room[r], 1u) == 0u) append(d.touched_room[p], &ctrl->n_touched_room[p], r);
             }
         }
     }
@@ -165,17 +167,18 @@ __device__ __forceinline__ bool building_draws(const Dev &d, uint32_t c, uint32_
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
     const bool atw = at_work && (fl & FL_HAS_WORK);
     const bool same = fl & FL_SAME_AREA;
+    const uint32_t *cnt_bld = d.cnt_bld[t & 1u], *cnt_room = d.cnt_room[t & 1u];
     // "If the Citizen is not currently in the Area, they haven't been exposed!" simulator.rs:324
     if (!atw || same) {
-        const uint32_t n = d.cnt_bld[d.home[c]];
+        const uint32_t n = cnt_bld[d.home[c]];
         if (n && esim_u53(seed, g, t, ESIM_SLOT_HOME) < threshold(d, fl, mask, n)) return true;
     }
     if ((fl & FL_HAS_WORK) && (at_work || same)) {
-        const uint32_t n = d.cnt_bld[d.work[c]];
+        const uint32_t n = cnt_bld[d.work[c]];
         if (n) {
             const uint64_t thr = threshold(d, fl, mask, n);
             if (fl & FL_WORK_SCHOOL) {
-                const uint32_t k = d.cnt_room[d.room[c]];               // one copy of the room per infected
+                const uint32_t k = cnt_room[d.room[c]];                 // one copy of the room per infected
                 for (uint32_t j = 0; j < k; ++j)
                     if (esim_u53(seed, g, t, ESIM_SLOT_ROOM0 + j) < thr) return true;
             } else if (esim_u53(seed, g, t, ESIM_SLOT_WORK) < thr) return true;
@@ -230,58 +233,74 @@ __device__ __forceinline__ void expose_phase(const Dev &d, Ctrl *ctrl, uint32_t 
     const uint32_t t = ctrl->t, mask = ctrl->mask;
     uint32_t at_work, bus_dir;
     schedule(d, ctrl, t, at_work, bus_dir);
-    const uint32_t nb = ld(&ctrl->n_touched_bld), nr = ld(&ctrl->n_touched_room), nrt = ld(&ctrl->n_touched_route);
+    const uint32_t p = t & 1u, q = p ^ 1u;
+    const uint32_t *cnt_bld = d.cnt_bld[p], *cnt_room = d.cnt_room[p];
+    const uint32_t nb = ld(&ctrl->n_touched_bld[p]), nr = ld(&ctrl->n_touched_room[p]), nrt = ld(&ctrl->n_touched_route[p]);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (vb * blockDim.x + threadIdx.x) >> 6, n_waves = (nvb * blockDim.x) >> 6;
     uint32_t n_exp = 0;
-    for (uint32_t it = wave; it < nb + nr + nrt; it += n_waves) {
+    // (0) forget the marks of the previous step (other parity); nobody reads them any more
+    {
+        const uint32_t tid = vb * blockDim.x + threadIdx.x, nth = nvb * blockDim.x;
+        const uint32_t ob = ctrl->n_touched_bld[q], orr = ctrl->n_touched_room[q], ort = ctrl->n_touched_route[q], orb = ctrl->n_touched_route_big[q];
+        for (uint32_t i = tid; i < ob; i += nth) d.cnt_bld[q][d.touched_bld[q][i]] = 0u;
+        for (uint32_t i = tid; i < orr; i += nth) d.cnt_room[q][d.touched_room[q][i]] = 0u;
+        for (uint32_t i = tid; i < ort; i += nth) d.route_flag[q][d.touched_route[q][i]] = 0u;
+        for (uint32_t i = tid; i < orb; i += nth) d.route_flag[q][d.touched_route_big[q][i]] = 0u;
+    }
+    // (1) marked buildings and school rooms: groups of 8 lanes per item, 8 items per wavefront pass
+    const uint32_t grp = lane >> 3, gl = lane & 7u;
+    for (uint32_t base = wave * 8u; base < nb + nr; base += n_waves * 8u) {
+        const uint32_t it = base + grp;
+        if (it >= nb + nr) continue;
         if (it < nb) {
-            const uint32_t b = d.touched_bld[it];
+            const uint32_t b = d.touched_bld[p][it];
             if (d.bld_type[b] == ESIM_SCHOOL) continue;                  // School::find_exposures works per room
-            const uint32_t n = d.cnt_bld[b];                             // exposure_count, simulator.rs:307
+            const uint32_t n = cnt_bld[b];                               // exposure_count, simulator.rs:307
             // Household / Workplace::find_exposures: every registered occupant (building.rs:202-204,278-280)
-            for (uint32_t k = d.res_off[b] + lane; k < d.res_off[b + 1]; k += 64u)
+            for (uint32_t k = d.res_off[b] + gl; k < d.res_off[b + 1]; k += 8u)
                 member_draw(d, ctrl, d.res_idx ? d.res_idx[k] : k, 0u, n, 0u, t, mask, at_work, n_exp);
-            for (uint32_t k = d.wrk_off[b] + lane; k < d.wrk_off[b + 1]; k += 64u)
+            for (uint32_t k = d.wrk_off[b] + gl; k < d.wrk_off[b + 1]; k += 8u)
                 member_draw(d, ctrl, d.wrk_idx[k], 1u, n, 0u, t, mask, at_work, n_exp);
-        } else if (it < nb + nr) {
-            const uint32_t r = d.touched_room[it - nb];
-            const uint32_t k = d.cnt_room[r];                            // one copy of the room per infected in it
-            const uint32_t n = d.cnt_bld[d.room_bld[r]];                 // infected in the whole school
-            for (uint32_t q = d.room_off[r] + lane; q < d.room_off[r + 1]; q += 64u)
-                member_draw(d, ctrl, d.room_idx[q], 2u, n, k, t, mask, at_work, n_exp);
         } else {
-            // route of <= 64 riders: rank by (Philox key, id) with shuffles; buses are consecutive runs of
-            // bus_capacity ranks (replaces shuffle + pop, simulator.rs:362-388)
-            const uint32_t r = d.touched_route[it - nb - nr];
-            const uint32_t off = d.route_off[r], s = d.route_off[r + 1] - off;
-            uint32_t c = 0, st = 0, key = 0;
-            bool inf = false;
-            if (lane < s) {
-                c = d.route_riders[off + lane];
-                st = d.state[c];
-                inf = status_of(st & ST_TE_MASK, t, d.exposed_time, d.infected_time) == ESIM_INFECTED;
-                key = philox4x32_10(d.id_base + c, t, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
-            }
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < s; ++j) {
-                const uint32_t kj = __shfl(key, j, 64);
-                rank += kj < key || (kj == key && j < lane);             // ids ascend with the lane
-            }
-            const uint32_t bus = rank / d.bus_capacity;
-            uint32_t k = 0;
-            for (uint32_t j = 0; j < s; ++j) {
-                const uint32_t bj = __shfl(bus, j, 64);
-                const bool ij = __shfl((int)inf, j, 64);
-                k += ij && bj == bus;
-            }
-            if (lane < s && k && (st & ST_TE_MASK) == TE_SUSCEPTIBLE) bus_draw(d, ctrl, c, k, t, mask, at_work);
+            const uint32_t r = d.touched_room[p][it - nb];
+            const uint32_t k = cnt_room[r];                              // one copy of the room per infected in it
+            const uint32_t n = cnt_bld[d.room_bld[r]];                   // infected in the whole school
+            for (uint32_t m = d.room_off[r] + gl; m < d.room_off[r + 1]; m += 8u)
+                member_draw(d, ctrl, d.room_idx[m], 2u, n, k, t, mask, at_work, n_exp);
         }
     }
+    // (2) marked routes of <= 64 riders, one wavefront each: rank by (Philox key, id) with shuffles; buses are
+    // consecutive runs of bus_capacity ranks (replaces shuffle + pop, simulator.rs:362-388)
+    for (uint32_t it = wave; it < nrt; it += n_waves) {
+        const uint32_t r = d.touched_route[p][it];
+        const uint32_t off = d.route_off[r], s = d.route_off[r + 1] - off;
+        uint32_t c = 0, st = 0, key = 0;
+        bool inf = false;
+        if (lane < s) {
+            c = d.route_riders[off + lane];
+            st = d.state[c];
+            inf = status_of(st & ST_TE_MASK, t, d.exposed_time, d.infected_time) == ESIM_INFECTED;
+            key = philox4x32_10(d.id_base + c, t, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
+        }
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < s; ++j) {
+            const uint32_t kj = __shfl(key, j, 64);
+            rank += kj < key || (kj == key && j < lane);                 // ids ascend with the lane
+        }
+        const uint32_t bus = rank / d.bus_capacity;
+        uint32_t k = 0;
+        for (uint32_t j = 0; j < s; ++j) {
+            const uint32_t bj = __shfl(bus, j, 64);
+            const bool ij = __shfl((int)inf, j, 64);
+            k += ij && bj == bus;
+        }
+        if (lane < s && k && (st & ST_TE_MASK) == TE_SUSCEPTIBLE) bus_draw(d, ctrl, c, k, t, mask, at_work);
+    }
     // routes of > 64 riders (rare: a very large Output Area): rank by counting through global scratch
-    const uint32_t nbig = ld(&ctrl->n_touched_route_big);
+    const uint32_t nbig = ld(&ctrl->n_touched_route_big[p]);
     for (uint32_t ri = vb; ri < nbig; ri += nvb) {
-        const uint32_t r = d.touched_route_big[ri];
+        const uint32_t r = d.touched_route_big[p][ri];
         const uint32_t off = d.route_off[r], s = d.route_off[r + 1] - off;
         for (uint32_t i = threadIdx.x; i < s; i += blockDim.x) {
             const uint32_t c = d.route_riders[off + i];
@@ -334,8 +353,9 @@ __global__ __launch_bounds__(TPB) void k_pack_a(Dev d)
         schedule(d, ctrl, ctrl->t, at_work, bus_dir);
         if (threadIdx.x < XA_HEADER) d.xa[threadIdx.x] = threadIdx.x < 5 ? cen[threadIdx.x] : (threadIdx.x == 5 && bus_dir ? d.n_pt : 0u);
     }
-    if (i < nb) { const int32_t l = d.shared_bld[i]; d.xa[XA_HEADER + i] = l >= 0 ? d.cnt_bld[l] : 0u; }
-    if (i < nr) { const int32_t l = d.shared_room[i]; d.xa[XA_HEADER + nb + i] = l >= 0 ? d.cnt_room[l] : 0u; }
+    const uint32_t p = ctrl->t & 1u;
+    if (i < nb) { const int32_t l = d.shared_bld[i]; d.xa[XA_HEADER + i] = l >= 0 ? d.cnt_bld[p][l] : 0u; }
+    if (i < nr) { const int32_t l = d.shared_room[i]; d.xa[XA_HEADER + nb + i] = l >= 0 ? d.cnt_room[p][l] : 0u; }
 }
 
 __global__ __launch_bounds__(TPB) void k_unpack_a(Dev d)
@@ -343,17 +363,18 @@ __global__ __launch_bounds__(TPB) void k_unpack_a(Dev d)
     Ctrl *ctrl = d.ctrl;
     const uint32_t i = blockIdx.x * TPB + threadIdx.x;
     const uint32_t nb = d.n_shared_bld, nr = d.n_shared_room;
+    const uint32_t p = ctrl->t & 1u;
     if (i < 5) ctrl->counts[i] = d.xa[i];
     if (i == 5) ctrl->n_riders = d.xa[5];
     if (i < nb) {
         const int32_t l = d.shared_bld[i];
         const uint32_t tot = d.xa[XA_HEADER + i];
-        if (l >= 0 && tot) { if (d.cnt_bld[l] == 0u) append(d.touched_bld, &ctrl->n_touched_bld, (uint32_t)l); d.cnt_bld[l] = tot; }
+        if (l >= 0 && tot) { if (d.cnt_bld[p][l] == 0u) append(d.touched_bld[p], &ctrl->n_touched_bld[p], (uint32_t)l); d.cnt_bld[p][l] = tot; }
     }
     if (i < nr) {
         const int32_t l = d.shared_room[i];
         const uint32_t tot = d.xa[XA_HEADER + nb + i];
-        if (l >= 0 && tot) { if (d.cnt_room[l] == 0u) append(d.touched_room, &ctrl->n_touched_room, (uint32_t)l); d.cnt_room[l] = tot; }
+        if (l >= 0 && tot) { if (d.cnt_room[p][l] == 0u) append(d.touched_room[p], &ctrl->n_touched_room[p], (uint32_t)l); d.cnt_room[p][l] = tot; }
     }
 }
 
@@ -556,12 +577,6 @@ __device__ __forceinline__ void finish_phase(const Dev &d, Ctrl *ctrl, int shard
             vacc_now = already;
         }
     }
-    // forget this step's marks
-    const uint32_t nb = ld(&ctrl->n_touched_bld), nr = ld(&ctrl->n_touched_room), nrt = ld(&ctrl->n_touched_route), nrb = ld(&ctrl->n_touched_route_big);
-    for (uint32_t i = tid; i < nb; i += FIN_TPB) d.cnt_bld[d.touched_bld[i]] = 0u;
-    for (uint32_t i = tid; i < nr; i += FIN_TPB) d.cnt_room[d.touched_room[i]] = 0u;
-    for (uint32_t i = tid; i < nrt; i += FIN_TPB) d.route_flag[d.touched_route[i]] = 0u;
-    for (uint32_t i = tid; i < nrb; i += FIN_TPB) d.route_flag[d.touched_route_big[i]] = 0u;
     __syncthreads();
     if (tid == 0) {
         const uint32_t exps = exp_bld + exp_bus;
@@ -590,7 +605,9 @@ __device__ __forceinline__ void finish_phase(const Dev &d, Ctrl *ctrl, int shard
         if (t <= d.max_steps) d.records[t] = r;
         ctrl->steps_done = t;
         if (!r.disease_exists && ctrl->stop_when_done) ctrl->finished = 1u;
-        ctrl->n_touched_bld = 0u; ctrl->n_touched_room = 0u; ctrl->n_touched_route = 0u; ctrl->n_touched_route_big = 0u;
+        // the marks of step t-1 were cleared by this step's k_expose: their lists are free for step t+1
+        const uint32_t q = (t & 1u) ^ 1u;
+        ctrl->n_touched_bld[q] = 0u; ctrl->n_touched_room[q] = 0u; ctrl->n_touched_route[q] = 0u; ctrl->n_touched_route_big[q] = 0u;
         ctrl->exp_bld = 0u; ctrl->exp_bus = 0u; ctrl->n_riders = 0u;
         for (int i = 0; i < 5; ++i) ctrl->counts[i] = 0u;
         ctrl->t = t + 1u;

@@ -201,10 +201,10 @@ class ShardedSimulator:
         _lib.check(self.lib.esim_enable_kernel_timing(self._ctx, int(stride)), self._ctx)
 
     def kernel_timings(self):
-        ms = (C.c_double * 3)()
+        ms = C.c_double(0)
         n = C.c_uint32(0)
-        _lib.check(self.lib.esim_kernel_timings(self._ctx, ms, C.byref(n)), self._ctx)
-        return {"k_infected_ms": ms[0], "k_expose_ms": ms[1], "k_finish_ms": ms[2], "launches": n.value}
+        _lib.check(self.lib.esim_kernel_timings(self._ctx, C.byref(ms), C.byref(n)), self._ctx)
+        return {"multi_kernel_step_ms": ms.value, "steps_timed": n.value}
 
     def set_small_step_limit(self, max_infected):
         _lib.check(self.lib.esim_set_small_step_limit(self._ctx, int(max_infected)), self._ctx)

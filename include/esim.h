@@ -185,13 +185,12 @@ int  esim_download_state(esim_ctx *ctx, uint8_t *status, uint16_t *timer,
 int  esim_enable_phase_timing(esim_ctx *ctx, int enable);
 int  esim_phase_timings(esim_ctx *ctx, double out[4]);
 
-/* Mean duration (ms) of the three kernels of a time step over the steps timed since the last call,
- * measured with hipEvents on the context's stream.  esim_enable_kernel_timing(ctx, n) brackets the
- * kernels of every n-th step (n = 0: off).
- *   out_ms[0] k_infected (generate_exposures), out_ms[1] k_expose (apply_exposures),
- *   out_ms[2] k_finish (apply_interventions + census); out_n = steps averaged. */
+/* Mean device time (ms) of a multi-workgroup time step -- HIP event before k_infected to HIP event after
+ * k_finish on the context's stream -- over the steps timed since the last call.
+ * esim_enable_kernel_timing(ctx, n) brackets every n-th such step (n = 0: off) and every launch of the
+ * persistent kernel (esim_small_kernel_timing). */
 int  esim_enable_kernel_timing(esim_ctx *ctx, int enable);
-int  esim_kernel_timings(esim_ctx *ctx, double out_ms[3], uint32_t *out_n);
+int  esim_kernel_timings(esim_ctx *ctx, double *step_ms, uint32_t *out_n);
 
 /* While few citizens are Infected a time step is a handful of dependent memory round trips; a persistent
  * single-workgroup kernel then advances many steps per launch (workgroup barriers instead of kernel

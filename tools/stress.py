@@ -8,7 +8,7 @@ ep = _lib.default_params(exposure_chance=0.004, lockdown_threshold=0.9, vaccinat
 sim = Simulator(pop, ep)
 sim.enable_kernel_timing(8)
 t0 = time.time(); g = sim.run(1200); dt = time.time() - t0
-print("gpu 1200 steps %.3fs -> %.3g citizen-steps/s" % (dt, pop.n_citizens * 1200 / dt), sim.kernel_timings())
+print("gpu 1200 steps %.3fs -> %.3g citizen-steps/s" % (dt, pop.n_citizens * 1200 / dt), sim.kernel_timings(), sim.small_kernel_timing())
 i = int(g['infected'].argmax()); print("peak infected", g['infected'][i], "at", g['time_step'][i], "final", g[['susceptible','exposed','infected','recovered','vaccinated']][-1])
 orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
 t0 = time.time(); o = orc.run(1200); print("oracle %.1fs" % (time.time() - t0))
