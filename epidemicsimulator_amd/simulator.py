@@ -67,7 +67,10 @@ def _memory_usage():
 class Simulator:
     """`Simulator::from(builder)` (simulator.rs:601-644): takes a built population."""
 
-    def __init__(self, population, params=None, area_code="synthetic"):
+    def __init__(self, population, params=None, area_code="synthetic", record_timings=False):
+        """record_timings: keep the reference's per-step function timers (statistics.rs:46-95,
+        simulator.rs:137,140,143) -- GPU time of the three phases from HIP events; costs one
+        synchronisation per step, so it is off unless asked for."""
         self.lib = _lib.load()
         self.area_code = area_code
         self.population = population
@@ -79,6 +82,11 @@ class Simulator:
         ps = population.as_struct()
         _lib.check(self.lib.esim_upload_population(self._ctx, C.byref(ps)), self._ctx)
         self._steps = 0
+        self.record_timings = bool(record_timings)
+        self._last_phase = None
+        if self.record_timings:
+            self.enable_phase_timing(True)
+            self._last_phase = self.phase_timings()
 
     # -- reference API -----------------------------------------------------------------
     def step(self):
@@ -87,7 +95,12 @@ class Simulator:
         _lib.check(self.lib.esim_step(self._ctx, C.byref(r)), self._ctx)
         self._steps += 1
         rec = r.as_dict()
-        self.statistics_recorder.push(rec)
+        timings = None
+        if self.record_timings:
+            now = self.phase_timings()
+            timings = {k: now[k] - self._last_phase[k] for k in now}
+            self._last_phase = now
+        self.statistics_recorder.push(rec, timings)
         self.last = rec
         return bool(rec["disease_exists"])
 

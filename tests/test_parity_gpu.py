@@ -102,6 +102,12 @@ def test_york_full_5000_steps_vaccination_85():
     run_both(Population.synthetic("york"), 5000, small_limits=(None,), vaccination_rate=85, vaccination_threshold=0.003)
 
 
+def test_yh_census_config_1500_steps():
+    # BASELINE.json configs[2]: Yorkshire & Humber (5 249 772 citizens, 17 246 Output Areas) on one GPU;
+    # 1500 of the 5000 steps keeps the oracle within ~20 s
+    run_both(Population.synthetic("yh_census"), 1500, small_limits=(None,))
+
+
 def test_big_routes_and_u8_truncation():
     # one very large Output Area: routes of > 64 riders (workgroup path), a school of > 256 members so the
     # infected count passes 255 (`as u8`, Q6), household and workplace draws in the same area
@@ -168,3 +174,28 @@ def test_size_independent_properties_large():
     st = s1.download_state()
     assert np.bincount(st["status"], minlength=5).tolist() != []      # decodes
     s1.close(); s2.close()
+
+
+def test_simulate_writes_the_reference_output_files(tmp_path):
+    # Simulator::simulate (simulator.rs:108-127) + StatisticsRecorder::dump_to_file (statistics.rs:113-150)
+    import json
+    pop = Population.synthetic("york", n_citizens=3000, n_areas=10, citizens_per_school=1500, n_seeds=8)
+    ep = _lib.default_params(max_steps=60, **{k: v for k, v in AGGRESSIVE.items()})
+    sim = Simulator(pop, ep, record_timings=True)
+    out = str(tmp_path) + "/run/"
+    sim.simulate(out)
+    stats = json.load(open(out + "global_stats.json"))
+    assert len(stats) == 61                                            # 60 steps + the all-zero entry of Q14
+    assert stats[-1] == {"time_step": 61, "susceptible": 0, "exposed": 0, "infected": 0, "recovered": 0, "vaccinated": 0}
+    assert set(stats[0]) == {"time_step", "susceptible", "exposed", "infected", "recovered", "vaccinated"}
+    orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep)).run(60)
+    for i in (0, 17, 59):
+        assert stats[i]["infected"] == int(orc["infected"][i]) and stats[i]["susceptible"] == int(orc["susceptible"][i])
+    timings = json.load(open(out + "timings.json"))
+    assert len(timings) == 60
+    assert set(timings[0]) == {"Generate Exposures", "Apply Exposures", "Apply Interventions", "total"}
+    assert all(t["total"] > 0 for t in timings)
+    exposures = json.load(open(out + "exposures.json"))
+    assert exposures["All"]["All"] == [int(a) + int(b) for a, b in zip(orc["exposures_building"], orc["exposures_bus"])]
+    assert len(json.load(open(out + "memory.json"))) == 60
+    sim.close()

@@ -78,3 +78,11 @@ def test_three_generated_shards_match_oracle():
                params=dict(AGGRESSIVE, seed=21), steps=500, chunk=250)
     outs = launch(3, cfg)
     assert all("ok" in o for o in outs)
+
+
+def test_syn3m5_two_generated_shards_match_oracle():
+    # BASELINE.json configs[3]: synthetic 3.5 M citizens, Output-Area sharded (here 2 ranks on the test GPU)
+    cfg = dict(backend="gloo", cuts="generated", spec=dict(n_citizens=3457142, n_areas=15669, citizens_per_school=20600, n_seeds=10),
+               params=dict(max_steps=800), steps=720, chunk=360)
+    outs = launch(2, cfg, timeout=500)
+    assert all("ok" in o for o in outs)
