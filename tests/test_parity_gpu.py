@@ -199,3 +199,44 @@ def test_simulate_writes_the_reference_output_files(tmp_path):
     assert exposures["All"]["All"] == [int(a) + int(b) for a, b in zip(orc["exposures_building"], orc["exposures_bus"])]
     assert len(json.load(open(out + "memory.json"))) == 60
     sim.close()
+
+
+def random_population(seed, n=700, n_areas=5, n_buildings=90, n_schools=3, rooms_per_school=4):
+    """Anything the ABI allows, not just what the reference's builder produces: workplaces in other areas,
+    people working in somebody's household, tiny and empty buildings, rooms with one member, citizens that
+    are not sorted by home (exercises res_idx), duplicate seeds."""
+    rng = np.random.default_rng(seed)
+    b_area = rng.integers(0, n_areas, n_buildings).astype(np.uint32)
+    b_type = rng.choice([_lib.HOUSEHOLD, _lib.WORKPLACE], n_buildings, p=[0.7, 0.3]).astype(np.uint8)
+    schools = rng.choice(n_buildings, n_schools, replace=False)
+    b_type[schools] = _lib.SCHOOL
+    room_bld = np.repeat(schools, rooms_per_school).astype(np.uint32)
+    not_school = np.nonzero(b_type != _lib.SCHOOL)[0]
+    home = rng.choice(not_school, n).astype(np.uint32)                 # unsorted on purpose
+    work = home.copy()
+    room = np.full(n, _lib.NO_ROOM, np.uint32)
+    kind = rng.random(n)
+    w = kind < 0.45                                                    # works in any non-school building, any area
+    work[w] = rng.choice(not_school, int(w.sum()))
+    sc = (kind >= 0.45) & (kind < 0.8)                                 # school member in a random room
+    r = rng.integers(0, len(room_bld), int(sc.sum()))
+    room[sc] = r
+    work[sc] = room_bld[r]
+    flags = (rng.random(n) < 0.5).astype(np.uint8) | ((rng.random(n) < 0.6).astype(np.uint8) << 1)
+    seeds = rng.integers(0, n, 9).astype(np.uint32)
+    seeds[-1] = seeds[0]
+    return Population(home_building=home, work_building=work, room=room, flags=flags, building_area=b_area,
+                      building_type=b_type, room_building=room_bld, seeds=seeds, n_areas=n_areas)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_populations_all_paths(seed):
+    pop = random_population(seed)
+    rng = np.random.default_rng(1000 + seed)
+    params = dict(exposure_chance=float(rng.choice([0.002, 0.01, 0.05])), seed=int(rng.integers(1, 1 << 40)),
+                  vaccination_rate=int(rng.choice([3, 25, 400])), vaccination_threshold=float(rng.choice([0.02, 0.08, 0.3])),
+                  lockdown_threshold=float(rng.choice([0.05, 0.15, 0.9])), mask_pt_threshold=0.02,
+                  mask_everywhere_threshold=float(rng.choice([0.04, 0.2])), bus_capacity=int(rng.choice([3, 20])),
+                  exposed_time=int(rng.choice([5, 96])), infected_time=int(rng.choice([17, 336])),
+                  start_hour=int(rng.choice([9, 6])), end_hour=int(rng.choice([17, 20])))
+    run_both(pop, 500, check_state_every=125, **params)
