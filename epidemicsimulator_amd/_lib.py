@@ -82,7 +82,8 @@ class SynthSpec(C.Structure):
 SYMBOLS = [
     "esim_default_params", "esim_create", "esim_upload_population", "esim_reset", "esim_step",
     "esim_run", "esim_step_begin", "esim_step_exposures", "esim_step_finish",
-    "esim_exchange_buffer", "esim_future_infected", "esim_run_free", "esim_read_records", "esim_stream", "esim_set_stream",
+    "esim_exchange_buffer", "esim_future_infected", "esim_run_free", "esim_set_pipeline", "esim_pipeline_timing",
+    "esim_read_records", "esim_stream", "esim_set_stream",
     "esim_set_exchange_buffer", "esim_synchronize",
     "esim_download_state", "esim_enable_phase_timing", "esim_phase_timings",
     "esim_enable_kernel_timing", "esim_kernel_timings", "esim_set_small_step_limit", "esim_small_kernel_timing",
@@ -117,7 +118,9 @@ def load():
         "esim_step_finish": (C.c_int, [vp, C.POINTER(StepResult)]),
         "esim_exchange_buffer": (C.c_int, [vp, C.c_int, pvp, C.POINTER(C.c_size_t)]),
         "esim_future_infected": (C.c_int, [vp]),
-        "esim_run_free": (C.c_int, [vp, C.c_uint32]),
+        "esim_run_free": (C.c_int, [vp, C.c_uint32, C.POINTER(C.c_uint32)]),
+        "esim_set_pipeline": (C.c_int, [vp, C.c_int]),
+        "esim_pipeline_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "esim_read_records": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(StepResult)]),
         "esim_stream": (C.c_int, [vp, pvp]),
         "esim_set_stream": (C.c_int, [vp, vp]),

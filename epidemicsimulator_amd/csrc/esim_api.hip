@@ -41,6 +41,8 @@ struct esim_ctx_impl {
     std::vector<hipEvent_t> kev;       // two per timed step: before k_infected, after k_finish
     size_t kev_used = 0;
     uint32_t grid_citizens = 1, grid_infected = 1, grid_expose = 1;
+    bool pipeline = true;              // run chunks of steps as one kernel per step while no vaccination programme runs
+    std::vector<hipEvent_t> pkev; size_t pkev_used = 0; uint64_t pipe_steps = 0;   // sampled k_pipe launches
     uint32_t small_max = 128;          // infected-slice length up to which the persistent single-workgroup kernel runs a step
     hipEvent_t sev[2] = { nullptr, nullptr };   // k_small timing
     double small_ms = 0; uint64_t small_steps = 0;
@@ -176,6 +178,7 @@ extern "C" void esim_destroy(esim_ctx *ctx)
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->kev) (void)hipEventDestroy(ev);
     for (auto &ev : c->sev) if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->pkev) (void)hipEventDestroy(ev);
     if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -299,10 +302,12 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     if ((rc = dev_upload(c, &d.bld_type, pop->building_type, B))) return rc;
     uint32_t *cnt = nullptr;
     const size_t per_parity = (size_t)B + R + n_routes;
-    if ((rc = dev_alloc(c, &cnt, 2 * per_parity))) return rc;
+    if ((rc = dev_alloc(c, &cnt, MARK_SLOTS * per_parity))) return rc;
     c->cnt_base = cnt;
-    c->cnt_bytes = sizeof(uint32_t) * 2 * per_parity;
-    for (int p = 0; p < 2; ++p) {
+    c->cnt_bytes = sizeof(uint32_t) * MARK_SLOTS * per_parity;
+    if ((rc = dev_alloc(c, &d.exp_step, 2 * ((size_t)c->P.max_steps + 2)))) return rc;
+    if ((rc = dev_alloc(c, &d.dec, FREE_MAX + 1))) return rc;
+    for (int p = 0; p < (int)MARK_SLOTS; ++p) {
         uint32_t *base = cnt + p * per_parity;
         d.cnt_bld[p] = base; d.cnt_room[p] = base + B; d.route_flag[p] = base + B + R;
         if ((rc = dev_alloc(c, &d.touched_bld[p], B))) return rc;
@@ -371,6 +376,7 @@ extern "C" int esim_reset(esim_ctx *ctx)
     HIP_TRY(c, hipMemcpy(d.ctrl, &h, sizeof h, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(d.state, c->init_state.data(), sizeof(uint16_t) * ((size_t)d.n + 2), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemset(c->cnt_base, 0, c->cnt_bytes));
+    HIP_TRY(c, hipMemset(d.exp_step, 0, sizeof(uint32_t) * 2 * ((size_t)c->P.max_steps + 2)));
     HIP_TRY(c, hipMemset(d.records, 0, sizeof(esim_step_result) * ((size_t)c->P.max_steps + 1)));
     // census histogram and exposure log: the seeds are Infected(0) before step 1, i.e. "exposed" at
     // step -(exposed_time + 1)
@@ -385,6 +391,7 @@ extern "C" int esim_reset(esim_ctx *ctx)
     c->phase_s[0] = c->phase_s[1] = c->phase_s[2] = 0;
     c->kev_used = 0;
     c->small_ms = 0; c->small_steps = 0;
+    c->pkev_used = 0; c->pipe_steps = 0;
     return ESIM_OK;
 }
 
@@ -500,10 +507,9 @@ extern "C" int esim_step(esim_ctx *ctx, esim_step_result *out);
 
 namespace {
 
-// Runs up to n_steps steps in `mode` (0 one shard, 2 free-running shard).  While few citizens are Infected
-// the persistent single-workgroup kernel advances many steps per launch; when a step's infected slice is
-// longer than small_max it returns and a chunk of steps goes through the multi-workgroup kernels.
-int run_steps(esim_ctx_impl *c, uint32_t n_steps, int mode, bool allow_early_stop, uint32_t *executed)
+// Sequential steps (three kernels per step, or the persistent single-workgroup kernel while few citizens
+// are Infected): the only form that can vaccinate.
+int run_sequential(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_t *executed)
 {
     Dev &d = c->d;
     uint32_t remaining = n_steps, total = 0;
@@ -511,14 +517,14 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, int mode, bool allow_early_sto
     while (remaining > 0) {
         if (c->small_max > 0 && !c->phase_timing) {
             if (c->kernel_timing) { if (!c->sev[0]) { (void)hipEventCreate(&c->sev[0]); (void)hipEventCreate(&c->sev[1]); } HIP_TRY(c, hipEventRecord(c->sev[0], c->stream)); }
-            hipLaunchKernelGGL(k_small, dim3(1), dim3(FIN_TPB), 0, c->stream, d, remaining, c->small_max, mode);
+            hipLaunchKernelGGL(k_small, dim3(1), dim3(FIN_TPB), 0, c->stream, d, remaining, c->small_max, 0);
             if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->sev[1], c->stream));
             Ctrl h;
             HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (c->kernel_timing && h.small_done) { float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->sev[0], c->sev[1])); c->small_ms += ms; c->small_steps += h.small_done; }
             c->host_t += h.small_done; total += h.small_done; remaining -= h.small_done;
-            if (h.error) return fail(c, -(int)h.error, "device-side error (S underflow / vaccination window exhausted / free run past the trigger)");
+            if (h.error) return fail(c, -(int)h.error, "device-side error (S underflow / vaccination window exhausted)");
             if (h.finished && allow_early_stop) break;
         }
         if (remaining == 0) break;
@@ -527,9 +533,82 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, int mode, bool allow_early_sto
             const bool tk = want_kernel_timing(c);
             if ((rc = enqueue_begin(c, tk))) return rc;
             if ((rc = enqueue_exposures(c, tk))) return rc;
-            if ((rc = enqueue_finish(c, tk, mode))) return rc;
+            if ((rc = enqueue_finish(c, tk, 0))) return rc;
         }
         total += chunk; remaining -= chunk;
+    }
+    if (executed) *executed = total;
+    return ESIM_OK;
+}
+
+// One pipelined chunk.  Precondition: k_future ran for the current step (and, when sharded, buffer F was
+// all-reduced).  k_decide finds how many of the next n_ahead steps can run before a vaccination programme
+// would start; those run as one k_pipe each and k_batch_finish writes their books.  *executed = steps run.
+int run_chunk(esim_ctx_impl *c, uint32_t n_ahead, uint32_t *executed, Ctrl *state_before)
+{
+    Dev &d = c->d;
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(1), 0, c->stream, d, n_ahead);
+    Ctrl h;
+    HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (state_before) *state_before = h;
+    if (h.error) return fail(c, -(int)h.error, "device-side error");
+    const uint32_t n = h.chunk_ok, t0 = h.t;
+    *executed = 0;
+    if (n == 0) return ESIM_OK;
+    hipLaunchKernelGGL(k_infected_dec, dim3(c->grid_infected), dim3(TPB), 0, c->stream, d, t0, 0u);
+    for (uint32_t j = 0; j < n; ++j) {
+        bool tk = c->kernel_timing && ((t0 + j) % c->kernel_timing_stride) == 0;
+        if (tk && c->pkev_used + 2 > c->pkev.size())
+            for (int i = 0; i < 2 && tk; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) tk = false; else c->pkev.push_back(e); }
+        if (tk) HIP_TRY(c, hipEventRecord(c->pkev[c->pkev_used], c->stream));
+        hipLaunchKernelGGL(k_pipe, dim3(c->grid_expose + c->grid_infected), dim3(TPB), 0, c->stream, d, t0 + j, j, c->grid_expose, j + 1 < n ? 1 : 0);
+        if (tk) { HIP_TRY(c, hipEventRecord(c->pkev[c->pkev_used + 1], c->stream)); c->pkev_used += 2; }
+    }
+    hipLaunchKernelGGL(k_batch_finish, dim3(1), dim3(FIN_TPB), 0, c->stream, d, t0, n);
+    HIP_TRY(c, hipGetLastError());
+    c->pipe_steps += n;
+    *executed = n;
+    return ESIM_OK;
+}
+
+// Runs up to n_steps steps of an unsharded context: pipelined chunks while no vaccination programme runs,
+// sequential steps from the step that starts it.
+int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_t *executed)
+{
+    Dev &d = c->d;
+    uint32_t remaining = n_steps, total = 0;
+    int rc;
+    bool sequential_only = !c->pipeline || c->phase_timing;
+    while (remaining > 0) {
+        if (sequential_only) {
+            uint32_t done = 0;
+            if ((rc = run_sequential(c, remaining, allow_early_stop, &done))) return rc;
+            total += done;
+            break;
+        }
+        const uint32_t n_ahead = std::min<uint32_t>(remaining, (uint32_t)c->xf_n);
+        hipLaunchKernelGGL(k_future, dim3(1), dim3(TPB), 0, c->stream, d, n_ahead);
+        uint32_t done = 0;
+        Ctrl before;
+        if ((rc = run_chunk(c, n_ahead, &done, &before))) return rc;
+        c->host_t = before.t + done; total += done; remaining -= done;
+        if (before.finished) break;
+        if (done < n_ahead && remaining > 0) {
+            if (before.have_elig || before.vacc_active) { sequential_only = true; continue; }
+            // the next step starts the vaccination programme (or a limit was hit): one sequential step, then look again
+            uint32_t one = 0;
+            if ((rc = run_sequential(c, 1, allow_early_stop, &one))) return rc;
+            total += one; remaining -= one;
+            if (one == 0) break;
+        }
+        if (allow_early_stop && done > 0) {
+            // a chunk may have ended the run (disease gone): k_batch_finish set `finished`
+            Ctrl h;
+            HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (h.finished) { c->host_t = h.t; break; }
+        }
     }
     if (executed) *executed = total;
     return ESIM_OK;
@@ -544,7 +623,7 @@ extern "C" int esim_step(esim_ctx *ctx, esim_step_result *out)
     if (rc) return rc;
     if (c->d.n_shards > 1) return fail(c, ESIM_ESTATE, "esim_step: a sharded population needs the split-phase calls and an all-reduce");
     HIP_TRY(c, hipSetDevice(c->P.device));
-    if ((rc = run_steps(c, 1, 0, false, nullptr))) return rc;
+    if ((rc = run_steps(c, 1, false, nullptr))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (out) HIP_TRY(c, hipMemcpy(out, &c->d.records[c->host_t - 1], sizeof *out, hipMemcpyDeviceToHost));
     return device_error(c);
@@ -560,7 +639,7 @@ extern "C" int esim_run(esim_ctx *ctx, uint32_t n_steps, int stop_when_done, esi
     const uint32_t first = c->host_t;
     const uint32_t flag = stop_when_done ? 1u : 0u;
     HIP_TRY(c, hipMemcpyAsync(&c->d.ctrl->stop_when_done, &flag, sizeof flag, hipMemcpyHostToDevice, c->stream));
-    if ((rc = run_steps(c, n_steps, 0, stop_when_done != 0, nullptr))) return rc;
+    if ((rc = run_steps(c, n_steps, stop_when_done != 0, nullptr))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     Ctrl h;
     HIP_TRY(c, hipMemcpy(&h, c->d.ctrl, sizeof h, hipMemcpyDeviceToHost));
@@ -583,7 +662,7 @@ extern "C" int esim_future_infected(esim_ctx *ctx)
     return ESIM_OK;
 }
 
-extern "C" int esim_run_free(esim_ctx *ctx, uint32_t n_steps)
+extern "C" int esim_run_free(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_done)
 {
     esim_ctx_impl *c = CTX(ctx);
     int rc = check_budget(c, n_steps);
@@ -591,7 +670,35 @@ extern "C" int esim_run_free(esim_ctx *ctx, uint32_t n_steps)
     if (n_steps > c->xf_n) return fail(c, ESIM_EINVAL, "esim_run_free: more steps than the future vector covers");
     if (c->d.n_shared_bld || c->d.n_shared_room) return fail(c, ESIM_ESTATE, "esim_run_free: shards that share buildings need the coupled steps");
     HIP_TRY(c, hipSetDevice(c->P.device));
-    return run_steps(c, n_steps, 2, false, nullptr);
+    uint32_t done = 0;
+    if ((rc = run_chunk(c, n_steps, &done, nullptr))) return rc;
+    c->host_t += done;
+    if (n_done) *n_done = done;
+    return ESIM_OK;
+}
+
+extern "C" int esim_set_pipeline(esim_ctx *ctx, int enable)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c) return ESIM_EINVAL;
+    c->pipeline = enable != 0;
+    return ESIM_OK;
+}
+
+extern "C" int esim_pipeline_timing(esim_ctx *ctx, double *mean_step_ms, uint64_t *steps_timed, uint64_t *steps_run)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c) return ESIM_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double acc = 0;
+    const size_t n = c->pkev_used / 2;
+    for (size_t i = 0; i < n; ++i) { float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->pkev[2 * i], c->pkev[2 * i + 1])); acc += ms; }
+    if (mean_step_ms) *mean_step_ms = n ? acc / (double)n : 0.0;
+    if (steps_timed) *steps_timed = n;
+    if (steps_run) *steps_run = c->pipe_steps;
+    c->pkev_used = 0; c->pipe_steps = 0;
+    return ESIM_OK;
 }
 
 extern "C" int esim_set_small_step_limit(esim_ctx *ctx, uint32_t max_infected)

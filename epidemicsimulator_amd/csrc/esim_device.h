@@ -33,6 +33,8 @@
 #define VACC_MAX_RATE 8192u
 #define NO_ROUTE 0xFFFFFFFFu
 
+#define MARK_SLOTS 4
+
 struct Ctrl {
     uint32_t t;                 // time step being processed (1-based; statistics.rs:167)
     uint32_t lockdown;          // InterventionStatus.lockdown.is_some() as decided at the end of step t-1
@@ -51,14 +53,21 @@ struct Ctrl {
     uint32_t n_susceptible, n_vaccinated, n_recovered_sentinel;
     uint32_t log_len;           // entries in the exposure log
     // per-step work lists (zeroed by k_finish)
-    // (double-buffered by step parity: the marks of step t are cleared by the multi-workgroup k_expose of step t+1)
-    uint32_t n_touched_bld[2], n_touched_room[2], n_touched_route[2], n_touched_route_big[2];
-    uint32_t exp_bld, exp_bus;
+    // (ring of MARK_SLOTS by step: the marks of step t are cleared by the exposure pass of step t+1)
+    uint32_t n_touched_bld[MARK_SLOTS], n_touched_room[MARK_SLOTS], n_touched_route[MARK_SLOTS], n_touched_route_big[MARK_SLOTS];
     uint32_t counts[5];         // census of the step in flight (global when sharded, after unpack)
     uint32_t n_riders;
     uint32_t free_base;         // first step of the current free-running batch (decoupled sharded mode)
     uint32_t small_done;        // steps executed by the last k_small launch
-    uint32_t pad[5];
+    uint32_t chunk_ok;          // steps of the current chunk that may run pipelined (k_decide)
+    uint32_t pad[6];
+};
+
+// What is in force during one step of a pipelined chunk (k_decide fills dec[0..chunk_ok]).
+struct Decision {
+    uint32_t lockdown;          // InterventionStatus.lockdown.is_some() while the step runs
+    uint32_t mask;              // mask_status while the step's exposures are drawn
+    uint32_t at_work, bus_dir;  // global position / bus direction after the step's schedule arm
 };
 
 struct Dev {
@@ -76,11 +85,13 @@ struct Dev {
     const uint32_t *room_off, *room_idx;    // participants per school room
     const uint32_t *room_bld;               // [n_room] school of each room
     const uint8_t  *bld_type;
-    // marks of a step, one set per step parity p = t & 1
-    uint32_t *cnt_bld[2];       // [n_bld] infected citizens standing in each building this step
-    uint32_t *cnt_room[2];      // [n_room] ... in each school room
-    uint32_t *touched_bld[2], *touched_room[2], *touched_route[2], *touched_route_big[2];
-    uint32_t *route_flag[2];    // [n_routes]
+    // marks of a step, one set per ring slot t % MARK_SLOTS
+    uint32_t *cnt_bld[MARK_SLOTS];       // [n_bld] infected citizens standing in each building this step
+    uint32_t *cnt_room[MARK_SLOTS];      // [n_room] ... in each school room
+    uint32_t *touched_bld[MARK_SLOTS], *touched_room[MARK_SLOTS], *touched_route[MARK_SLOTS], *touched_route_big[MARK_SLOTS];
+    uint32_t *route_flag[MARK_SLOTS];    // [n_routes]
+    uint32_t *exp_step;         // [2 * (max_steps + 2)] successful exposures per step: [2t] buildings, [2t+1] buses
+    struct Decision *dec;       // [FREE_MAX + 1]
     uint32_t *hist;             // [TE_SLOTS] citizens per exposure time (census without a pass over citizens)
     uint32_t *log;              // exposure log: citizen ids in order of exposure step
     uint32_t *log_off;          // [TE_SLOTS + 1] first log entry whose te >= k

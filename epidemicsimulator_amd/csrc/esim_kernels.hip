@@ -7,6 +7,12 @@
 //               walk its registered members exactly as Building::find_exposures does and draw
 //   k_finish    apply_interventions (simulator.rs:455-556), the census and the StatisticEntry
 //
+// While no vaccination programme runs, everything a step needs from the past except the exposures of the
+// previous step is known up to exposed_time steps ahead (who is Infected, where everybody stands, the
+// intervention decisions).  Then steps run as ONE kernel each (k_pipe: exposures of step t, marks of step
+// t+1 and clearing of step t-1's marks side by side) and the books of a whole chunk of <= 96 steps are
+// written by k_batch_finish (k_future / k_decide prepare the chunk).
+//
 // Work-efficient by construction:
 //  * DiseaseStatus is a function of (step - exposure step), so the census of simulator.rs:178 is a
 //    sliding-window sum over a histogram of exposure steps, not a pass over citizens;
@@ -21,6 +27,7 @@
 #include "philox.h"
 
 #define TPB 256
+#define FIN_TPB 1024
 
 __device__ __forceinline__ uint32_t status_of(uint32_t te, uint32_t t, uint32_t et, uint32_t it)
 {
@@ -53,6 +60,26 @@ __device__ __forceinline__ void schedule(const Dev &d, const Ctrl *ctrl, uint32_
     else if (h == d.end_hour - 1u) bus_dir = 2u;                  // :191-196
     else if (h == d.end_hour) { at_work = 0u; bus_dir = 0u; }     // :198-201
     else bus_dir = 0u;                                            // :202-204
+}
+
+// What is in force while step t runs: taken from the control block (one step at a time) or from the
+// decision table of a pipelined chunk.
+struct StepEnv { uint32_t t, mask, at_work, bus_dir; };
+
+__device__ __forceinline__ StepEnv env_from_ctrl(const Dev &d, const Ctrl *ctrl)
+{
+    StepEnv e;
+    e.t = ctrl->t; e.mask = ctrl->mask;
+    schedule(d, ctrl, e.t, e.at_work, e.bus_dir);
+    return e;
+}
+
+__device__ __forceinline__ StepEnv env_from_dec(const Dev &d, uint32_t t, uint32_t j)
+{
+    const Decision q = d.dec[j];
+    StepEnv e;
+    e.t = t; e.mask = q.mask; e.at_work = q.at_work; e.bus_dir = q.bus_dir;
+    return e;
 }
 
 // Census of simulator.rs:178 from the exposure-time histogram; called by a whole block.
@@ -90,15 +117,13 @@ __device__ __forceinline__ void append(uint32_t *list, uint32_t *len, uint32_t v
 // The Infected citizens of step t are the log slice with exposure step in
 // [t - exposed_time - 1 - infected_time, t - exposed_time - 1].  simulator.rs:181-198: a rider
 // joins its route's session, anybody else marks current_building_position.
-__device__ __forceinline__ void infected_phase(const Dev &d, Ctrl *ctrl, uint32_t vb, uint32_t nvb)
+__device__ __forceinline__ void infected_phase(const Dev &d, Ctrl *ctrl, const StepEnv &env, uint32_t vb, uint32_t nvb)
 {
-    const uint32_t t = ctrl->t;
-    uint32_t at_work, bus_dir;
-    schedule(d, ctrl, t, at_work, bus_dir);
+    const uint32_t t = env.t, at_work = env.at_work, bus_dir = env.bus_dir;
     const int hi = (int)(t + TE_BIAS) - (int)d.exposed_time - 1;
     const int lo = hi - (int)d.infected_time;
     if (hi < 0) return;
-    const uint32_t p = t & 1u;
+    const uint32_t p = t & (MARK_SLOTS - 1u);
     uint32_t *cnt_bld = d.cnt_bld[p], *cnt_room = d.cnt_room[p], *route_flag = d.route_flag[p];
     const uint32_t i0 = d.log_off[lo < 0 ? 0 : lo], i1 = d.log_off[hi + 1];
     for (uint32_t i = i0 + vb * blockDim.x + threadIdx.x; i < i1; i += nvb * blockDim.x) {
@@ -126,7 +151,7 @@ __device__ __forceinline__ void infected_phase(const Dev &d, Ctrl *ctrl, uint32_
 __global__ __launch_bounds__(TPB) void k_infected(Dev d)
 {
     if (d.ctrl->finished) return;
-    infected_phase(d, d.ctrl, blockIdx.x, gridDim.x);
+    infected_phase(d, d.ctrl, env_from_ctrl(d, d.ctrl), blockIdx.x, gridDim.x);
 }
 
 // Threshold for Citizen::expose (citizen.rs:221-248): row 1 of the LUT is p - p*mask_effectiveness,
@@ -167,7 +192,7 @@ __device__ __forceinline__ bool building_draws(const Dev &d, uint32_t c, uint32_
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
     const bool atw = at_work && (fl & FL_HAS_WORK);
     const bool same = fl & FL_SAME_AREA;
-    const uint32_t *cnt_bld = d.cnt_bld[t & 1u], *cnt_room = d.cnt_room[t & 1u];
+    const uint32_t *cnt_bld = d.cnt_bld[t & (MARK_SLOTS - 1u)], *cnt_room = d.cnt_room[t & (MARK_SLOTS - 1u)];
     // "If the Citizen is not currently in the Area, they haven't been exposed!" simulator.rs:324
     if (!atw || same) {
         const uint32_t n = cnt_bld[d.home[c]];
@@ -218,7 +243,7 @@ __device__ __forceinline__ void bus_draw(const Dev &d, Ctrl *ctrl, uint32_t c, u
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
     if (esim_u53(seed, d.id_base + c, t, ESIM_SLOT_BUS) < threshold(d, fl, mask, k)) {
         if (expose_once(d, ctrl, c, (t + TE_BIAS) | ST_BUS_EXPOSED)) {
-            atomicAdd(&ctrl->exp_bus, 1u);
+            atomicAdd(&d.exp_step[2u * t + 1u], 1u);
             if (ctrl->have_elig) atomicSub(&ctrl->elig_count, 1u);       // simulator.rs:447-449 (a Susceptible is eligible)
         }
     }
@@ -228,12 +253,10 @@ __device__ __forceinline__ void bus_draw(const Dev &d, Ctrl *ctrl, uint32_t c, u
 // apply_exposures.  Work items: marked buildings (residents + workers), marked school rooms,
 // marked routes of <= 64 riders -- one wavefront each, lanes over the members; then marked
 // routes of > 64 riders, one workgroup each.
-__device__ __forceinline__ void expose_phase(const Dev &d, Ctrl *ctrl, uint32_t vb, uint32_t nvb)
+__device__ __forceinline__ void expose_phase(const Dev &d, Ctrl *ctrl, const StepEnv &env, uint32_t vb, uint32_t nvb)
 {
-    const uint32_t t = ctrl->t, mask = ctrl->mask;
-    uint32_t at_work, bus_dir;
-    schedule(d, ctrl, t, at_work, bus_dir);
-    const uint32_t p = t & 1u, q = p ^ 1u;
+    const uint32_t t = env.t, mask = env.mask, at_work = env.at_work;
+    const uint32_t p = t & (MARK_SLOTS - 1u), q = (t + MARK_SLOTS - 1u) & (MARK_SLOTS - 1u);
     const uint32_t *cnt_bld = d.cnt_bld[p], *cnt_room = d.cnt_room[p];
     const uint32_t nb = ld(&ctrl->n_touched_bld[p]), nr = ld(&ctrl->n_touched_room[p]), nrt = ld(&ctrl->n_touched_route[p]);
     const uint32_t lane = threadIdx.x & 63u;
@@ -329,13 +352,13 @@ __device__ __forceinline__ void expose_phase(const Dev &d, Ctrl *ctrl, uint32_t 
         }
         __syncthreads();
     }
-    if (n_exp) atomicAdd(&ctrl->exp_bld, n_exp);
+    if (n_exp) atomicAdd(&d.exp_step[2u * t], n_exp);
 }
 
 __global__ __launch_bounds__(TPB) void k_expose(Dev d)
 {
     if (d.ctrl->finished) return;
-    expose_phase(d, d.ctrl, blockIdx.x, gridDim.x);
+    expose_phase(d, d.ctrl, env_from_ctrl(d, d.ctrl), blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------- exchange
@@ -353,7 +376,7 @@ __global__ __launch_bounds__(TPB) void k_pack_a(Dev d)
         schedule(d, ctrl, ctrl->t, at_work, bus_dir);
         if (threadIdx.x < XA_HEADER) d.xa[threadIdx.x] = threadIdx.x < 5 ? cen[threadIdx.x] : (threadIdx.x == 5 && bus_dir ? d.n_pt : 0u);
     }
-    const uint32_t p = ctrl->t & 1u;
+    const uint32_t p = ctrl->t & (MARK_SLOTS - 1u);
     if (i < nb) { const int32_t l = d.shared_bld[i]; d.xa[XA_HEADER + i] = l >= 0 ? d.cnt_bld[p][l] : 0u; }
     if (i < nr) { const int32_t l = d.shared_room[i]; d.xa[XA_HEADER + nb + i] = l >= 0 ? d.cnt_room[p][l] : 0u; }
 }
@@ -363,7 +386,7 @@ __global__ __launch_bounds__(TPB) void k_unpack_a(Dev d)
     Ctrl *ctrl = d.ctrl;
     const uint32_t i = blockIdx.x * TPB + threadIdx.x;
     const uint32_t nb = d.n_shared_bld, nr = d.n_shared_room;
-    const uint32_t p = ctrl->t & 1u;
+    const uint32_t p = ctrl->t & (MARK_SLOTS - 1u);
     if (i < 5) ctrl->counts[i] = d.xa[i];
     if (i == 5) ctrl->n_riders = d.xa[5];
     if (i < nb) {
@@ -407,8 +430,9 @@ __global__ __launch_bounds__(TPB) void k_pack_b(Dev d)
     const bool trig = !ctrl->vacc_active && d.thr_vacc < (double)ctrl->counts[2] / (double)total;
     const uint32_t tstep = trig ? t : ctrl->trigger_step;
     if (i == 0) {
-        d.xb[0] = ctrl->exp_bld; d.xb[1] = ctrl->exp_bus;
-        d.xb[2] = trig ? ctrl->n_susceptible - ctrl->exp_bld - ctrl->exp_bus : ctrl->elig_count;
+        const uint32_t eb = d.exp_step[2u * t], eu = d.exp_step[2u * t + 1u];
+        d.xb[0] = eb; d.xb[1] = eu;
+        d.xb[2] = trig ? ctrl->n_susceptible - eb - eu : ctrl->elig_count;
         d.xb[3] = ctrl->error;
     }
     if (i < VACC_BATCH) {
@@ -420,14 +444,16 @@ __global__ __launch_bounds__(TPB) void k_pack_b(Dev d)
     }
 }
 
-// Decoupled sharded mode.  A citizen exposed in step t is Infected no earlier than step t + exposed_time + 1,
-// so after step t0 the Infected census of steps t0+1 .. t0+exposed_time+1 is already fixed (as long as nobody is
-// vaccinated).  Shards therefore exchange that vector once per batch instead of a census every step; the
-// intervention decisions of the batch (interventions.rs:110-184 needs only the infected fraction) then read it.
+// ------------------------------------------------------------------------------- chunk set-up
+// A citizen exposed in step t is Infected no earlier than step t + exposed_time + 1 (disease.rs:47-71), so the
+// Infected census of the next <= exposed_time + 1 steps is already fixed -- as long as nobody is vaccinated.
+// k_future writes that vector for this shard (sharded runs SUM-all-reduce it); k_decide then runs the
+// intervention state machine (interventions.rs:110-184 needs nothing but the infected fraction) and the
+// schedule (citizen.rs:176-206) over the chunk and stops in front of the step that would start vaccinating.
 __global__ __launch_bounds__(TPB) void k_future(Dev d, uint32_t n_ahead)
 {
     Ctrl *ctrl = d.ctrl;
-    const uint32_t t0 = ctrl->t;                                           // first step of the batch
+    const uint32_t t0 = ctrl->t;                                           // first step of the chunk
     for (uint32_t j = threadIdx.x; j < n_ahead; j += TPB) {
         const int hi = (int)(t0 + j + TE_BIAS) - (int)d.exposed_time - 1;
         const int lo = hi - (int)d.infected_time;
@@ -436,6 +462,136 @@ __global__ __launch_bounds__(TPB) void k_future(Dev d, uint32_t n_ahead)
         d.xf[j] = s;
     }
     if (threadIdx.x == 0) ctrl->free_base = t0;
+}
+
+__global__ void k_decide(Dev d, uint32_t n_ahead)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t t0 = ctrl->t;
+    uint32_t lockdown = ctrl->lockdown, mask = ctrl->mask, at_work = ctrl->at_work, bus_dir = ctrl->bus_dir;
+    uint32_t n_ok = 0;
+    if (!ctrl->have_elig && !ctrl->vacc_active && !ctrl->finished && !ctrl->error && ctrl->free_base == t0) {
+        for (uint32_t j = 0; j < n_ahead && j < FREE_MAX && t0 + j <= d.max_steps; ++j) {
+            const double x = (double)d.xf[j] / (double)d.n_global;        // infected_percentage, statistics.rs:252
+            if (d.thr_vacc < x) break;                                    // this step starts the programme: not pipelined
+            if (!lockdown) {                                              // citizen.rs:176-206
+                const uint32_t h = (t0 + j) % 24u;
+                if (h == d.start_hour - 1u) bus_dir = 1u;
+                else if (h == d.start_hour) { at_work = 1u; bus_dir = 0u; }
+                else if (h == d.end_hour - 1u) bus_dir = 2u;
+                else if (h == d.end_hour) { at_work = 0u; bus_dir = 0u; }
+                else bus_dir = 0u;
+            }
+            Decision q; q.lockdown = lockdown; q.mask = mask; q.at_work = at_work; q.bus_dir = bus_dir;
+            d.dec[j] = q;
+            lockdown = d.thr_lockdown < x ? 1u : 0u;                      // interventions.rs:116-128
+            if (mask == ESIM_MASK_NONE) { if (d.thr_mask_pt < x) mask = ESIM_MASK_PUBLIC_TRANSPORT; }   // :142-180
+            else if (mask == ESIM_MASK_PUBLIC_TRANSPORT) {
+                if (x < d.thr_mask_pt) mask = ESIM_MASK_NONE;
+                else if (d.thr_mask_all < x) mask = ESIM_MASK_EVERYWHERE;
+            } else if (x < d.thr_mask_all) mask = ESIM_MASK_PUBLIC_TRANSPORT;
+            n_ok = j + 1u;
+        }
+    }
+    Decision q; q.lockdown = lockdown; q.mask = mask; q.at_work = at_work; q.bus_dir = bus_dir;
+    d.dec[n_ok] = q;                                                      // what is in force after the chunk
+    ctrl->chunk_ok = n_ok;
+}
+
+// Marks of the first step of a chunk (the later ones are made by the k_pipe of the step before).
+__global__ __launch_bounds__(TPB) void k_infected_dec(Dev d, uint32_t t, uint32_t j)
+{
+    infected_phase(d, d.ctrl, env_from_dec(d, t, j), blockIdx.x, gridDim.x);
+}
+
+// ------------------------------------------------------------------------------------- k_pipe
+// One pipelined step: workgroups [0, n_expose) draw the exposures of step t (and clear the marks of step
+// t-1), the others mark for step t+1.  The two halves touch different ring slots and different state:
+// marks of t+1 depend on citizens exposed >= exposed_time + 1 steps ago, never on step t's exposures.
+__global__ __launch_bounds__(TPB) void k_pipe(Dev d, uint32_t t, uint32_t j, uint32_t n_expose, int mark_next)
+{
+    Ctrl *ctrl = d.ctrl;
+    if (blockIdx.x < n_expose) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            // slot (t+2) was cleared by the previous k_pipe; its lists restart empty for the k_pipe after this one
+            const uint32_t z = (t + 2u) & (MARK_SLOTS - 1u);
+            ctrl->n_touched_bld[z] = 0u; ctrl->n_touched_room[z] = 0u; ctrl->n_touched_route[z] = 0u; ctrl->n_touched_route_big[z] = 0u;
+        }
+        expose_phase(d, ctrl, env_from_dec(d, t, j), blockIdx.x, n_expose);
+    } else if (mark_next) {
+        infected_phase(d, ctrl, env_from_dec(d, t + 1u, j + 1u), blockIdx.x - n_expose, gridDim.x - n_expose);
+    }
+}
+
+// ----------------------------------------------------------------------------- k_batch_finish
+// The books of a pipelined chunk [t0, t0+n): census (simulator.rs:178) by sliding the Exposed / Infected
+// windows over the exposure histogram, the StatisticEntry of every step (statistics.rs:208-215, adjusted
+// by citizen_exposed :275-287), hist / log offsets, and the control block as it stands after the chunk.
+#define BF_WIN 1024
+__global__ __launch_bounds__(FIN_TPB) void k_batch_finish(Dev d, uint32_t t0, uint32_t n)
+{
+    __shared__ uint32_t win[BF_WIN];                   // hist[base_idx + i]
+    __shared__ uint32_t eb[FREE_MAX], eu[FREE_MAX], off[FREE_MAX];
+    __shared__ esim_step_result recs[FREE_MAX];
+    __shared__ uint32_t n_eff_s;
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t tid = threadIdx.x;
+    const int et = (int)d.exposed_time, it = (int)d.infected_time;
+    const int base_idx = (int)(t0 + TE_BIAS) - et - 1 - it;              // lowest histogram entry any census of the chunk reads
+    const int span = et + it + 2 + (int)n;                               // .. up to t0 + n - 1 + TE_BIAS
+    for (int i = (int)tid; i < span && i < BF_WIN; i += FIN_TPB) { const int k = base_idx + i; win[i] = k >= 0 ? d.hist[k] : 0u; }
+    if (tid < n) { eb[tid] = d.exp_step[2u * (t0 + tid)]; eu[tid] = d.exp_step[2u * (t0 + tid) + 1u]; }
+    __syncthreads();
+    if (tid == 0) {
+        auto W = [&](int k) -> uint32_t & { return win[k - base_idx]; };
+        uint32_t S = ctrl->n_susceptible;
+        const uint32_t V = ctrl->n_vaccinated;
+        uint32_t E = 0, I = 0;
+        const int top = (int)(t0 + TE_BIAS);
+        for (int k = top - et; k <= top; ++k) E += W(k);
+        for (int k = top - et - 1 - it; k <= top - et - 1; ++k) I += W(k);
+        uint32_t run = d.log_off[t0 + TE_BIAS];
+        uint32_t n_eff = n;
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t s = t0 + j;
+            const int ts = (int)(s + TE_BIAS);
+            const uint32_t exps = eb[j] + eu[j];
+            esim_step_result r;
+            r.time_step = s;
+            if (exps > S) ctrl->error = (uint32_t)(-ESIM_ESIM);          // citizen_exposed underflow
+            r.susceptible = S - exps; r.exposed = E + exps; r.infected = I;
+            r.recovered = d.n - S - V - E - I; r.vaccinated = V;
+            r.exposures_building = eb[j]; r.exposures_bus = eu[j];
+            r.lockdown = d.dec[j + 1u].lockdown; r.vaccination_active = 0u; r.mask_status = d.dec[j + 1u].mask;
+            r.n_riders = d.dec[j].bus_dir ? d.n_pt : 0u; r.vaccinated_now = 0u; r.eligible_count = 0u;
+            r.disease_exists = (r.exposed != 0u || r.infected != 0u || r.susceptible != 0u) ? 1u : 0u;
+            r.reserved = 0u;
+            recs[j] = r;
+            // this step's exposures enter the books, then both windows slide to step s + 1
+            S -= exps; W(ts) += exps; run += exps; off[j] = run;
+            E = E + exps - W(ts - et);
+            I = I + W(ts - et) - W(ts - et - 1 - it);
+            if (!r.disease_exists && ctrl->stop_when_done) { n_eff = j + 1u; ctrl->finished = 1u; break; }
+        }
+        n_eff_s = n_eff;
+        ctrl->n_susceptible = S;
+        ctrl->t = t0 + n_eff; ctrl->steps_done = t0 + n_eff - 1u;
+        ctrl->lockdown = d.dec[n_eff].lockdown; ctrl->mask = d.dec[n_eff].mask;
+        ctrl->at_work = d.dec[n_eff - 1u].at_work; ctrl->bus_dir = d.dec[n_eff - 1u].bus_dir;
+        // ring slots: only the last step's marks stay (the next exposure pass clears them)
+        const uint32_t keep = (t0 + n - 1u) & (MARK_SLOTS - 1u);
+        for (uint32_t z = 0; z < MARK_SLOTS; ++z)
+            if (z != keep) { ctrl->n_touched_bld[z] = 0u; ctrl->n_touched_room[z] = 0u; ctrl->n_touched_route[z] = 0u; ctrl->n_touched_route_big[z] = 0u; }
+    }
+    __syncthreads();
+    const uint32_t n_eff = n_eff_s;
+    if (tid < n_eff) {
+        const uint32_t s = t0 + tid;
+        d.hist[s + TE_BIAS] = win[(int)(s + TE_BIAS) - base_idx];
+        d.log_off[s + TE_BIAS + 1u] = off[tid];
+        if (s <= d.max_steps) d.records[s] = recs[tid];
+    }
 }
 
 // Vaccination bookkeeping for one citizen set to Vaccinated (simulator.rs:551).
@@ -454,7 +610,6 @@ __device__ __forceinline__ void vaccinate(const Dev &d, Ctrl *ctrl, uint32_t c)
 // apply_interventions (simulator.rs:455-556): InterventionStatus::update_status
 // (interventions.rs:110-184), the vaccination draw (simulator.rs:524-553), the StatisticEntry of the
 // step (statistics.rs:208-215, adjusted by citizen_exposed :275-287), and the hand-over to step t+1.
-#define FIN_TPB 1024
 struct FinishShared {
     uint32_t tab_key[VACC_TABLE];
     uint32_t tab_idx[VACC_TABLE];
@@ -475,25 +630,16 @@ __device__ __forceinline__ void finish_phase(const Dev &d, Ctrl *ctrl, int shard
     const uint32_t t = ctrl->t;
     uint32_t at_work, bus_dir;
     schedule(d, ctrl, t, at_work, bus_dir);
-    // sharded: 0 one shard; 1 coupled (global census from exchange A); 2 free-running batch (local census,
-    // the global Infected count of this step comes from the exchanged future vector)
-    const bool free_run = sharded == 2;
-    if (free_run) sharded = 0;
-    if (sharded) { if (tid < 5) cen[tid] = ctrl->counts[tid]; __syncthreads(); }     // global census from exchange A
+    // sharded: 0 one shard (local census is the census); 1 coupled shards (global census from exchange A)
+    if (sharded) { if (tid < 5) cen[tid] = ctrl->counts[tid]; __syncthreads(); }
     else census_block(d, ctrl, t, cen);
     const uint32_t total = cen[0] + cen[1] + cen[2] + cen[3] + cen[4];
-    const double x = free_run ? (double)d.xf[t - ctrl->free_base] / (double)d.n_global
-                              : (double)cen[2] / (double)total;          // infected_percentage, statistics.rs:252
-    bool trig = !ctrl->vacc_active && d.thr_vacc < x;
-    if (free_run && (trig || ctrl->have_elig || t - ctrl->free_base >= FREE_MAX)) {
-        // the host must switch to the coupled mode before the vaccination programme starts
-        if (tid == 0) ctrl->error = (uint32_t)(-ESIM_ESTATE);
-        trig = false;
-    }
+    const double x = (double)cen[2] / (double)total;                     // infected_percentage, statistics.rs:252
+    const bool trig = !ctrl->vacc_active && d.thr_vacc < x;
     const bool have = ctrl->have_elig || trig;
     const uint32_t tstep = trig ? t : ctrl->trigger_step;
     // totals over all shards come from exchange buffer B when sharded, the ctrl fields stay per-shard
-    const uint32_t my_exp_bld = ld(&ctrl->exp_bld), my_exp_bus = ld(&ctrl->exp_bus);
+    const uint32_t my_exp_bld = ld(&d.exp_step[2u * t]), my_exp_bus = ld(&d.exp_step[2u * t + 1u]);
     const uint32_t exp_bld = sharded ? d.xb[0] : my_exp_bld;
     const uint32_t exp_bus = sharded ? d.xb[1] : my_exp_bus;
     const uint32_t local_elig = trig ? ld(&ctrl->n_susceptible) - my_exp_bld - my_exp_bus : ld(&ctrl->elig_count);
@@ -605,10 +751,10 @@ __device__ __forceinline__ void finish_phase(const Dev &d, Ctrl *ctrl, int shard
         if (t <= d.max_steps) d.records[t] = r;
         ctrl->steps_done = t;
         if (!r.disease_exists && ctrl->stop_when_done) ctrl->finished = 1u;
-        // the marks of step t-1 were cleared by this step's k_expose: their lists are free for step t+1
-        const uint32_t q = (t & 1u) ^ 1u;
+        // the marks of step t-1 were cleared by this step's exposure pass: that slot's lists are free again
+        const uint32_t q = (t + MARK_SLOTS - 1u) & (MARK_SLOTS - 1u);
         ctrl->n_touched_bld[q] = 0u; ctrl->n_touched_room[q] = 0u; ctrl->n_touched_route[q] = 0u; ctrl->n_touched_route_big[q] = 0u;
-        ctrl->exp_bld = 0u; ctrl->exp_bus = 0u; ctrl->n_riders = 0u;
+        ctrl->n_riders = 0u;
         for (int i = 0; i < 5; ++i) ctrl->counts[i] = 0u;
         ctrl->t = t + 1u;
     }
@@ -647,9 +793,10 @@ __global__ __launch_bounds__(FIN_TPB) void k_small(Dev d, uint32_t max_steps, ui
         }
         __syncthreads();
         if (!go) break;                                   // block-uniform: every wave leaves together
-        infected_phase(d, ctrl, 0u, 1u);
+        const StepEnv env = env_from_ctrl(d, ctrl);
+        infected_phase(d, ctrl, env, 0u, 1u);
         __syncthreads();
-        expose_phase(d, ctrl, 0u, 1u);
+        expose_phase(d, ctrl, env, 0u, 1u);
         __syncthreads();
         finish_phase(d, ctrl, mode, sm);
     }

@@ -115,24 +115,22 @@ class ShardedSimulator:
             self._steps += n_steps
             return
         torch, dist = self.torch, self.dist
-        thr = float(self.params.vaccination_threshold)
         done = 0
         with torch.cuda.stream(self.stream):
             while done < n_steps:
                 if self.mode_free:
                     _lib.check(lib.esim_future_infected(ctx), ctx)
                     dist.all_reduce(self.xbuf[2], group=self.group)
-                    future = self.xbuf[2].cpu().numpy().astype(np.int64)      # the one host sync per batch
-                    over = np.nonzero(thr < future / float(self.n_citizens_global))[0]
-                    n_free = int(over[0]) if over.size else self.free_batch
-                    n_free = min(n_free, n_steps - done)
+                    want = min(self.free_batch, n_steps - done)
+                    got = C.c_uint32(0)
+                    _lib.check(lib.esim_run_free(ctx, want, C.byref(got)), ctx)   # one host sync per chunk inside
+                    n_free = got.value
                     if n_free > 0:
-                        _lib.check(lib.esim_run_free(ctx, n_free), ctx)
                         self._local_ranges.append((self._steps + 1, self._steps + n_free))
                         self._steps += n_free
                         self.free_steps += n_free
                         done += n_free
-                    if over.size and done < n_steps:
+                    if n_free < want:
                         self.mode_free = False        # the programme starts in the next step: coupled from here on
                     continue
                 _lib.check(lib.esim_step_begin(ctx), ctx)
@@ -208,6 +206,15 @@ class ShardedSimulator:
 
     def set_small_step_limit(self, max_infected):
         _lib.check(self.lib.esim_set_small_step_limit(self._ctx, int(max_infected)), self._ctx)
+
+    def set_pipeline(self, on):
+        """Pipelined chunks (one kernel per step while no vaccination programme runs) on/off."""
+        _lib.check(self.lib.esim_set_pipeline(self._ctx, int(bool(on))), self._ctx)
+
+    def pipeline_timing(self):
+        ms, nt, nr = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self.lib.esim_pipeline_timing(self._ctx, C.byref(ms), C.byref(nt), C.byref(nr)), self._ctx)
+        return {"k_pipe_ms": ms.value, "steps_timed": nt.value, "steps": nr.value}
 
     def small_kernel_timing(self):
         ms, n = C.c_double(0), C.c_uint64(0)

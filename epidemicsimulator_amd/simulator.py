@@ -160,6 +160,15 @@ class Simulator:
         (0 = always use the multi-workgroup kernels)."""
         _lib.check(self.lib.esim_set_small_step_limit(self._ctx, int(max_infected)), self._ctx)
 
+    def set_pipeline(self, on):
+        """Pipelined chunks (one kernel per step while no vaccination programme runs) on/off."""
+        _lib.check(self.lib.esim_set_pipeline(self._ctx, int(bool(on))), self._ctx)
+
+    def pipeline_timing(self):
+        ms, nt, nr = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self.lib.esim_pipeline_timing(self._ctx, C.byref(ms), C.byref(nt), C.byref(nr)), self._ctx)
+        return {"k_pipe_ms": ms.value, "steps_timed": nt.value, "steps": nr.value}
+
     def small_kernel_timing(self):
         ms, n = C.c_double(0), C.c_uint64(0)
         _lib.check(self.lib.esim_small_kernel_timing(self._ctx, C.byref(ms), C.byref(n)), self._ctx)

@@ -144,17 +144,21 @@ int  esim_step_begin(esim_ctx *ctx);
 int  esim_step_exposures(esim_ctx *ctx);
 int  esim_step_finish(esim_ctx *ctx, esim_step_result *out /* may be NULL */);
 int  esim_exchange_buffer(esim_ctx *ctx, int which /* 0 = A, 1 = B, 2 = F */, void **device_ptr, size_t *n_u32);
-/* Decoupled form for shards that share no building (n_shared_* == 0) while no vaccination programme runs.
- * A citizen exposed in step t is Infected no earlier than t + exposed_time + 1 (disease.rs:47-71), so after
- * step t0 every shard already knows its Infected census of steps t0+1 .. t0+n (n = size of buffer F <=
- * exposed_time + 1), and the interventions (interventions.rs:110-184) need nothing else from other shards:
+/* Pipelined chunks.  A citizen exposed in step t is Infected no earlier than t + exposed_time + 1
+ * (disease.rs:47-71).  Hence, while no vaccination programme runs, the Infected census -- and with it every
+ * intervention decision (interventions.rs:110-184), the schedule (citizen.rs:176-206) and who marks which
+ * building -- is known for the next n <= exposed_time + 1 steps (n = size of buffer F, at most 96).  esim_run
+ * uses this by itself (one kernel per step, books written once per chunk).  Shards that share no building
+ * (n_shared_* == 0) use it to run without per-step collectives:
  *   esim_future_infected -- writes this shard's Infected census of the next n steps into buffer F
- *   [SUM all-reduce of F; the caller may read it to find the step at which vaccination would trigger]
- *   esim_run_free(k)     -- k <= n whole steps without any exchange; records hold THIS shard's census
- * The caller must return to the coupled steps before the step whose infected fraction exceeds
- * vaccination_threshold (the device flags ESIM_ESTATE otherwise). */
+ *   [SUM all-reduce of F over the shards]
+ *   esim_run_free(k, &done) -- runs min(k, steps before the one that would start vaccinating) whole steps
+ *                              with no exchange; records hold THIS shard's census; done < k means the next
+ *                              step must be a coupled one (esim_step_begin / _exposures / _finish).
+ * esim_set_pipeline(ctx, 0) makes esim_run / esim_step use sequential steps only. */
 int  esim_future_infected(esim_ctx *ctx);
-int  esim_run_free(esim_ctx *ctx, uint32_t n_steps);
+int  esim_run_free(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_done);
+int  esim_set_pipeline(esim_ctx *ctx, int enable);
 /* Record log read-back for split-phase runs (records first..first+n-1, 1-based time steps). */
 int  esim_read_records(esim_ctx *ctx, uint32_t first_step, uint32_t n, esim_step_result *out);
 /* The HIP stream all work of this context is enqueued on (hipStream_t as void*).  esim_set_stream
@@ -199,6 +203,9 @@ int  esim_kernel_timings(esim_ctx *ctx, double *step_ms, uint32_t *out_n);
  * steps of those launches while kernel timing is enabled, then resets the accumulators. */
 int  esim_set_small_step_limit(esim_ctx *ctx, uint32_t max_infected);
 int  esim_small_kernel_timing(esim_ctx *ctx, double *total_ms, uint64_t *steps);
+/* Pipelined steps: mean duration (ms) of the sampled k_pipe launches, how many were sampled, how many steps ran
+ * pipelined since the last call. */
+int  esim_pipeline_timing(esim_ctx *ctx, double *mean_step_ms, uint64_t *steps_timed, uint64_t *steps_run);
 
 const char *esim_last_error(const esim_ctx *ctx);   /* ctx may be NULL: last esim_create error */
 void esim_destroy(esim_ctx *ctx);
