@@ -355,6 +355,8 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     c->grid_citizens = grid_for(N, TPB, 2048);
     c->grid_infected = 1024;
     c->grid_expose = 1024;
+    if (const char *e = std::getenv("ESIM_GRID_INFECTED")) c->grid_infected = (uint32_t)std::max(1, std::atoi(e));   // tuning knobs
+    if (const char *e = std::getenv("ESIM_GRID_EXPOSE")) c->grid_expose = (uint32_t)std::max(1, std::atoi(e));
     c->uploaded = true;
     return esim_reset(ctx);
 }
@@ -547,7 +549,7 @@ int run_sequential(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, ui
 int run_chunk(esim_ctx_impl *c, uint32_t n_ahead, uint32_t *executed, Ctrl *state_before)
 {
     Dev &d = c->d;
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(1), 0, c->stream, d, n_ahead);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(128), 0, c->stream, d, n_ahead);
     Ctrl h;
     HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -588,7 +590,7 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             break;
         }
         const uint32_t n_ahead = std::min<uint32_t>(remaining, (uint32_t)c->xf_n);
-        hipLaunchKernelGGL(k_future, dim3(1), dim3(TPB), 0, c->stream, d, n_ahead);
+        hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, d, n_ahead);
         uint32_t done = 0;
         Ctrl before;
         if ((rc = run_chunk(c, n_ahead, &done, &before))) return rc;
@@ -657,7 +659,7 @@ extern "C" int esim_future_infected(esim_ctx *ctx)
     esim_ctx_impl *c = CTX(ctx);
     if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "no population uploaded");
     HIP_TRY(c, hipSetDevice(c->P.device));
-    hipLaunchKernelGGL(k_future, dim3(1), dim3(TPB), 0, c->stream, c->d, (uint32_t)c->xf_n);
+    hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, c->d, (uint32_t)c->xf_n);
     HIP_TRY(c, hipGetLastError());
     return ESIM_OK;
 }

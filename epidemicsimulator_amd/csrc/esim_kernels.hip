@@ -212,14 +212,12 @@ __device__ __forceinline__ bool building_draws(const Dev &d, uint32_t c, uint32_
     return false;
 }
 
-// One candidate of one member list (simulator.rs:308-350 for one citizen_id of find_exposures).
-// kind 0: resident (home list), 1: worker (work list), 2: room participant (k draws).
-__device__ __forceinline__ void member_draw(const Dev &d, Ctrl *ctrl, uint32_t m, uint32_t kind, uint32_t n, uint32_t k,
-                                            uint32_t t, uint32_t mask, uint32_t at_work, uint32_t &n_exp)
+// One candidate of one member list (simulator.rs:308-350 for one citizen_id of find_exposures), given its
+// state and flags.  kind 0: resident (home list), 1: worker (work list), 2: room participant (k draws).
+__device__ __forceinline__ void member_eval(const Dev &d, Ctrl *ctrl, uint32_t m, uint32_t st, uint32_t fl, uint32_t kind,
+                                            uint32_t n, uint32_t k, uint32_t t, uint32_t mask, uint32_t at_work, uint32_t &n_exp)
 {
-    const uint32_t st = d.state[m];
     if ((st & ST_TE_MASK) != TE_SUSCEPTIBLE) return;                     // is_susceptible(), simulator.rs:337
-    const uint32_t fl = d.flags[m];
     const bool same = fl & FL_SAME_AREA;
     // area of current_building_position == area of this building?  simulator.rs:324
     if (kind == 0u) { if (at_work && (fl & FL_HAS_WORK) && !same) return; }
@@ -231,6 +229,27 @@ __device__ __forceinline__ void member_draw(const Dev &d, Ctrl *ctrl, uint32_t m
     if (kind == 2u) { for (uint32_t j = 0; j < k && !hit; ++j) hit = esim_u53(seed, g, t, ESIM_SLOT_ROOM0 + j) < thr; }
     else hit = esim_u53(seed, g, t, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK) < thr;
     if (hit && expose_once(d, ctrl, m, t + TE_BIAS)) n_exp++;            // Exposed(0), citizen.rs:244
+}
+
+// Members [lo, hi) of one list, walked by a group of 8 lanes (gl = lane in group): every lane takes up to four
+// members per pass and issues their index / state / flag loads together, so a 30-member room costs one
+// dependent chain instead of four.
+__device__ __forceinline__ void member_list(const Dev &d, Ctrl *ctrl, const uint32_t *idx, uint32_t lo, uint32_t hi, uint32_t gl,
+                                            uint32_t kind, uint32_t n, uint32_t k, uint32_t t, uint32_t mask, uint32_t at_work,
+                                            uint32_t &n_exp)
+{
+    for (uint32_t base = lo + gl; base < hi; base += 32u) {
+        uint32_t m[4], st[4], fl[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint32_t q = base + 8u * u; ok[u] = q < hi; m[u] = ok[u] ? (idx ? idx[q] : q) : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) st[u] = ok[u] ? d.state[m[u]] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fl[u] = (ok[u] && (st[u] & ST_TE_MASK) == TE_SUSCEPTIBLE) ? d.flags[m[u]] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (ok[u]) member_eval(d, ctrl, m[u], st[u], fl[u], kind, n, k, t, mask, at_work, n_exp);
+    }
 }
 
 // A rider that the building phase leaves Susceptible draws once with the number of infected
@@ -281,16 +300,13 @@ __device__ __forceinline__ void expose_phase(const Dev &d, Ctrl *ctrl, const Ste
             if (d.bld_type[b] == ESIM_SCHOOL) continue;                  // School::find_exposures works per room
             const uint32_t n = cnt_bld[b];                               // exposure_count, simulator.rs:307
             // Household / Workplace::find_exposures: every registered occupant (building.rs:202-204,278-280)
-            for (uint32_t k = d.res_off[b] + gl; k < d.res_off[b + 1]; k += 8u)
-                member_draw(d, ctrl, d.res_idx ? d.res_idx[k] : k, 0u, n, 0u, t, mask, at_work, n_exp);
-            for (uint32_t k = d.wrk_off[b] + gl; k < d.wrk_off[b + 1]; k += 8u)
-                member_draw(d, ctrl, d.wrk_idx[k], 1u, n, 0u, t, mask, at_work, n_exp);
+            member_list(d, ctrl, d.res_idx, d.res_off[b], d.res_off[b + 1], gl, 0u, n, 0u, t, mask, at_work, n_exp);
+            member_list(d, ctrl, d.wrk_idx, d.wrk_off[b], d.wrk_off[b + 1], gl, 1u, n, 0u, t, mask, at_work, n_exp);
         } else {
             const uint32_t r = d.touched_room[p][it - nb];
             const uint32_t k = cnt_room[r];                              // one copy of the room per infected in it
             const uint32_t n = cnt_bld[d.room_bld[r]];                   // infected in the whole school
-            for (uint32_t m = d.room_off[r] + gl; m < d.room_off[r + 1]; m += 8u)
-                member_draw(d, ctrl, d.room_idx[m], 2u, n, k, t, mask, at_work, n_exp);
+            member_list(d, ctrl, d.room_idx, d.room_off[r], d.room_off[r + 1], gl, 2u, n, k, t, mask, at_work, n_exp);
         }
     }
     // (2) marked routes of <= 64 riders, one wavefront each: rank by (Philox key, id) with shuffles; buses are
@@ -450,53 +466,83 @@ __global__ __launch_bounds__(TPB) void k_pack_b(Dev d)
 // k_future writes that vector for this shard (sharded runs SUM-all-reduce it); k_decide then runs the
 // intervention state machine (interventions.rs:110-184 needs nothing but the infected fraction) and the
 // schedule (citizen.rs:176-206) over the chunk and stops in front of the step that would start vaccinating.
-__global__ __launch_bounds__(TPB) void k_future(Dev d, uint32_t n_ahead)
+// Inclusive prefix sum over BF_WIN values in shared memory, by a workgroup of FIN_TPB = BF_WIN threads.
+#define BF_WIN 1024
+__device__ __forceinline__ void block_scan_1024(uint32_t *v, uint32_t *wtmp)
 {
-    Ctrl *ctrl = d.ctrl;
-    const uint32_t t0 = ctrl->t;                                           // first step of the chunk
-    for (uint32_t j = threadIdx.x; j < n_ahead; j += TPB) {
-        const int hi = (int)(t0 + j + TE_BIAS) - (int)d.exposed_time - 1;
-        const int lo = hi - (int)d.infected_time;
-        uint32_t s = 0;
-        for (int k = lo < 0 ? 0 : lo; k <= hi; ++k) s += d.hist[k];
-        d.xf[j] = s;
-    }
-    if (threadIdx.x == 0) ctrl->free_base = t0;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    uint32_t x = v[tid];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= (uint32_t)o) x += y; }
+    if (lane == 63u) wtmp[wv] = x;
+    __syncthreads();
+    if (tid == 0) { uint32_t a = 0; for (uint32_t w = 0; w < FIN_TPB / 64; ++w) { const uint32_t y = wtmp[w]; wtmp[w] = a; a += y; } }
+    __syncthreads();
+    v[tid] = x + wtmp[wv];
+    __syncthreads();
 }
 
-__global__ void k_decide(Dev d, uint32_t n_ahead)
+__global__ __launch_bounds__(FIN_TPB) void k_future(Dev d, uint32_t n_ahead)
 {
-    if (threadIdx.x || blockIdx.x) return;
+    __shared__ uint32_t win[BF_WIN];
+    __shared__ uint32_t wtmp[FIN_TPB / 64];
     Ctrl *ctrl = d.ctrl;
-    const uint32_t t0 = ctrl->t;
-    uint32_t lockdown = ctrl->lockdown, mask = ctrl->mask, at_work = ctrl->at_work, bus_dir = ctrl->bus_dir;
-    uint32_t n_ok = 0;
-    if (!ctrl->have_elig && !ctrl->vacc_active && !ctrl->finished && !ctrl->error && ctrl->free_base == t0) {
-        for (uint32_t j = 0; j < n_ahead && j < FREE_MAX && t0 + j <= d.max_steps; ++j) {
-            const double x = (double)d.xf[j] / (double)d.n_global;        // infected_percentage, statistics.rs:252
-            if (d.thr_vacc < x) break;                                    // this step starts the programme: not pipelined
-            if (!lockdown) {                                              // citizen.rs:176-206
-                const uint32_t h = (t0 + j) % 24u;
-                if (h == d.start_hour - 1u) bus_dir = 1u;
-                else if (h == d.start_hour) { at_work = 1u; bus_dir = 0u; }
-                else if (h == d.end_hour - 1u) bus_dir = 2u;
-                else if (h == d.end_hour) { at_work = 0u; bus_dir = 0u; }
-                else bus_dir = 0u;
-            }
-            Decision q; q.lockdown = lockdown; q.mask = mask; q.at_work = at_work; q.bus_dir = bus_dir;
-            d.dec[j] = q;
-            lockdown = d.thr_lockdown < x ? 1u : 0u;                      // interventions.rs:116-128
-            if (mask == ESIM_MASK_NONE) { if (d.thr_mask_pt < x) mask = ESIM_MASK_PUBLIC_TRANSPORT; }   // :142-180
-            else if (mask == ESIM_MASK_PUBLIC_TRANSPORT) {
-                if (x < d.thr_mask_pt) mask = ESIM_MASK_NONE;
-                else if (d.thr_mask_all < x) mask = ESIM_MASK_EVERYWHERE;
-            } else if (x < d.thr_mask_all) mask = ESIM_MASK_PUBLIC_TRANSPORT;
-            n_ok = j + 1u;
-        }
+    const uint32_t t0 = ctrl->t, tid = threadIdx.x;                        // t0: first step of the chunk
+    const int et = (int)d.exposed_time, it = (int)d.infected_time;
+    const int base_idx = (int)(t0 + TE_BIAS) - et - 1 - it;               // lowest entry of the first Infected window
+    { const int k = base_idx + (int)tid; win[tid] = (k >= 0 && k < (int)TE_SLOTS) ? d.hist[k] : 0u; }
+    __syncthreads();
+    block_scan_1024(win, wtmp);                                            // win[i] = sum of hist[base_idx .. base_idx + i]
+    if (tid < n_ahead) {
+        // Infected window of step t0 + tid: entries [tid, tid + it] of the loaded range
+        const uint32_t hi = win[tid + (uint32_t)it], lo = tid ? win[tid - 1u] : 0u;
+        d.xf[tid] = hi - lo;
     }
-    Decision q; q.lockdown = lockdown; q.mask = mask; q.at_work = at_work; q.bus_dir = bus_dir;
-    d.dec[n_ok] = q;                                                      // what is in force after the chunk
-    ctrl->chunk_ok = n_ok;
+    if (tid == 0) ctrl->free_base = t0;
+}
+
+__global__ __launch_bounds__(128) void k_decide(Dev d, uint32_t n_ahead)
+{
+    __shared__ double xs[FREE_MAX];
+    __shared__ Decision ds[FREE_MAX + 1];
+    Ctrl *ctrl = d.ctrl;
+    if (threadIdx.x < FREE_MAX) xs[threadIdx.x] = threadIdx.x < n_ahead ? (double)d.xf[threadIdx.x] / (double)d.n_global : 0.0;
+    __syncthreads();
+    __shared__ uint32_t n_ok_s;
+    if (threadIdx.x == 0) {
+        const uint32_t t0 = ctrl->t;
+        uint32_t lockdown = ctrl->lockdown, mask = ctrl->mask, at_work = ctrl->at_work, bus_dir = ctrl->bus_dir;
+        uint32_t n_ok = 0;
+        if (!ctrl->have_elig && !ctrl->vacc_active && !ctrl->finished && !ctrl->error && ctrl->free_base == t0) {
+            for (uint32_t j = 0; j < n_ahead && j < FREE_MAX && t0 + j <= d.max_steps; ++j) {
+                const double x = xs[j];                                       // infected_percentage, statistics.rs:252
+                if (d.thr_vacc < x) break;                                    // this step starts the programme: not pipelined
+                if (!lockdown) {                                              // citizen.rs:176-206
+                    const uint32_t h = (t0 + j) % 24u;
+                    if (h == d.start_hour - 1u) bus_dir = 1u;
+                    else if (h == d.start_hour) { at_work = 1u; bus_dir = 0u; }
+                    else if (h == d.end_hour - 1u) bus_dir = 2u;
+                    else if (h == d.end_hour) { at_work = 0u; bus_dir = 0u; }
+                    else bus_dir = 0u;
+                }
+                Decision q; q.lockdown = lockdown; q.mask = mask; q.at_work = at_work; q.bus_dir = bus_dir;
+                ds[j] = q;
+                lockdown = d.thr_lockdown < x ? 1u : 0u;                      // interventions.rs:116-128
+                if (mask == ESIM_MASK_NONE) { if (d.thr_mask_pt < x) mask = ESIM_MASK_PUBLIC_TRANSPORT; }   // :142-180
+                else if (mask == ESIM_MASK_PUBLIC_TRANSPORT) {
+                    if (x < d.thr_mask_pt) mask = ESIM_MASK_NONE;
+                    else if (d.thr_mask_all < x) mask = ESIM_MASK_EVERYWHERE;
+                } else if (x < d.thr_mask_all) mask = ESIM_MASK_PUBLIC_TRANSPORT;
+                n_ok = j + 1u;
+            }
+        }
+        Decision q; q.lockdown = lockdown; q.mask = mask; q.at_work = at_work; q.bus_dir = bus_dir;
+        ds[n_ok] = q;                                                         // what is in force after the chunk
+        n_ok_s = n_ok;
+        ctrl->chunk_ok = n_ok;
+    }
+    __syncthreads();
+    if (threadIdx.x <= n_ok_s) d.dec[threadIdx.x] = ds[threadIdx.x];
 }
 
 // Marks of the first step of a chunk (the later ones are made by the k_pipe of the step before).
@@ -528,69 +574,67 @@ __global__ __launch_bounds__(TPB) void k_pipe(Dev d, uint32_t t, uint32_t j, uin
 // The books of a pipelined chunk [t0, t0+n): census (simulator.rs:178) by sliding the Exposed / Infected
 // windows over the exposure histogram, the StatisticEntry of every step (statistics.rs:208-215, adjusted
 // by citizen_exposed :275-287), hist / log offsets, and the control block as it stands after the chunk.
-#define BF_WIN 1024
 __global__ __launch_bounds__(FIN_TPB) void k_batch_finish(Dev d, uint32_t t0, uint32_t n)
 {
-    __shared__ uint32_t win[BF_WIN];                   // hist[base_idx + i]
-    __shared__ uint32_t eb[FREE_MAX], eu[FREE_MAX], off[FREE_MAX];
-    __shared__ esim_step_result recs[FREE_MAX];
+    __shared__ uint32_t P[BF_WIN + 1];                 // P[i + 1] = sum of H[0..i], P[0] = 0
+    __shared__ uint32_t wtmp[FIN_TPB / 64];
     __shared__ uint32_t n_eff_s;
     Ctrl *ctrl = d.ctrl;
     const uint32_t tid = threadIdx.x;
     const int et = (int)d.exposed_time, it = (int)d.infected_time;
     const int base_idx = (int)(t0 + TE_BIAS) - et - 1 - it;              // lowest histogram entry any census of the chunk reads
-    const int span = et + it + 2 + (int)n;                               // .. up to t0 + n - 1 + TE_BIAS
-    for (int i = (int)tid; i < span && i < BF_WIN; i += FIN_TPB) { const int k = base_idx + i; win[i] = k >= 0 ? d.hist[k] : 0u; }
-    if (tid < n) { eb[tid] = d.exp_step[2u * (t0 + tid)]; eu[tid] = d.exp_step[2u * (t0 + tid) + 1u]; }
+    // H[i] = citizens exposed in "step" base_idx + i: the histogram before the chunk, this chunk's exposure counters inside it
+    {
+        const int k = base_idx + (int)tid;
+        uint32_t h = 0;
+        if (k >= (int)(t0 + TE_BIAS)) { const uint32_t j = (uint32_t)(k - (int)(t0 + TE_BIAS)); if (j < n) h = d.exp_step[2u * (t0 + j)] + d.exp_step[2u * (t0 + j) + 1u]; }
+        else if (k >= 0) h = d.hist[k];
+        P[tid + 1] = h;
+        if (tid == 0) { P[0] = 0u; n_eff_s = n; }
+    }
     __syncthreads();
+    block_scan_1024(P + 1, wtmp);
+    const uint32_t S0 = ctrl->n_susceptible, V = ctrl->n_vaccinated, run0 = d.log_off[t0 + TE_BIAS];
+    const int top0 = (int)(t0 + TE_BIAS) - base_idx;                      // index of hist[t0 + TE_BIAS] in H
+    esim_step_result r;
+    uint32_t exps = 0;
+    if (tid < n) {
+        const uint32_t s = t0 + tid;
+        const int ts = top0 + (int)tid;                                   // index of this step's own entry
+        exps = P[ts + 1] - P[ts];
+        const uint32_t S = S0 - (P[ts] - P[top0]);                         // Susceptible before this step's exposures
+        const uint32_t E = P[ts] - P[ts - et];                             // exposed in steps s - et .. s - 1 (census precedes exposures)
+        const uint32_t I = P[ts - et] - P[ts - et - 1 - it];
+        r.time_step = s;
+        if (exps > S) ctrl->error = (uint32_t)(-ESIM_ESIM);               // citizen_exposed underflow, statistics.rs:275-287
+        r.susceptible = S - exps; r.exposed = E + exps; r.infected = I;
+        r.recovered = d.n - S - V - E - I; r.vaccinated = V;
+        r.exposures_building = d.exp_step[2u * s]; r.exposures_bus = d.exp_step[2u * s + 1u];
+        r.lockdown = d.dec[tid + 1u].lockdown; r.vaccination_active = 0u; r.mask_status = d.dec[tid + 1u].mask;
+        r.n_riders = d.dec[tid].bus_dir ? d.n_pt : 0u; r.vaccinated_now = 0u; r.eligible_count = 0u;
+        r.disease_exists = (r.exposed != 0u || r.infected != 0u || r.susceptible != 0u) ? 1u : 0u;   // statistics.rs:289-291
+        r.reserved = 0u;
+        if (!r.disease_exists && ctrl->stop_when_done) atomicMin(&n_eff_s, tid + 1u);
+    }
+    __syncthreads();
+    const uint32_t n_eff = n_eff_s;
+    if (tid < n_eff) {
+        const uint32_t s = t0 + tid;
+        const int ts = top0 + (int)tid;
+        d.hist[s + TE_BIAS] = exps;
+        d.log_off[s + TE_BIAS + 1u] = run0 + (P[ts + 1] - P[top0]);
+        if (s <= d.max_steps) d.records[s] = r;
+    }
     if (tid == 0) {
-        auto W = [&](int k) -> uint32_t & { return win[k - base_idx]; };
-        uint32_t S = ctrl->n_susceptible;
-        const uint32_t V = ctrl->n_vaccinated;
-        uint32_t E = 0, I = 0;
-        const int top = (int)(t0 + TE_BIAS);
-        for (int k = top - et; k <= top; ++k) E += W(k);
-        for (int k = top - et - 1 - it; k <= top - et - 1; ++k) I += W(k);
-        uint32_t run = d.log_off[t0 + TE_BIAS];
-        uint32_t n_eff = n;
-        for (uint32_t j = 0; j < n; ++j) {
-            const uint32_t s = t0 + j;
-            const int ts = (int)(s + TE_BIAS);
-            const uint32_t exps = eb[j] + eu[j];
-            esim_step_result r;
-            r.time_step = s;
-            if (exps > S) ctrl->error = (uint32_t)(-ESIM_ESIM);          // citizen_exposed underflow
-            r.susceptible = S - exps; r.exposed = E + exps; r.infected = I;
-            r.recovered = d.n - S - V - E - I; r.vaccinated = V;
-            r.exposures_building = eb[j]; r.exposures_bus = eu[j];
-            r.lockdown = d.dec[j + 1u].lockdown; r.vaccination_active = 0u; r.mask_status = d.dec[j + 1u].mask;
-            r.n_riders = d.dec[j].bus_dir ? d.n_pt : 0u; r.vaccinated_now = 0u; r.eligible_count = 0u;
-            r.disease_exists = (r.exposed != 0u || r.infected != 0u || r.susceptible != 0u) ? 1u : 0u;
-            r.reserved = 0u;
-            recs[j] = r;
-            // this step's exposures enter the books, then both windows slide to step s + 1
-            S -= exps; W(ts) += exps; run += exps; off[j] = run;
-            E = E + exps - W(ts - et);
-            I = I + W(ts - et) - W(ts - et - 1 - it);
-            if (!r.disease_exists && ctrl->stop_when_done) { n_eff = j + 1u; ctrl->finished = 1u; break; }
-        }
-        n_eff_s = n_eff;
-        ctrl->n_susceptible = S;
+        ctrl->n_susceptible = S0 - (P[top0 + (int)n_eff] - P[top0]);
         ctrl->t = t0 + n_eff; ctrl->steps_done = t0 + n_eff - 1u;
+        if (n_eff < n) ctrl->finished = 1u;
         ctrl->lockdown = d.dec[n_eff].lockdown; ctrl->mask = d.dec[n_eff].mask;
         ctrl->at_work = d.dec[n_eff - 1u].at_work; ctrl->bus_dir = d.dec[n_eff - 1u].bus_dir;
         // ring slots: only the last step's marks stay (the next exposure pass clears them)
         const uint32_t keep = (t0 + n - 1u) & (MARK_SLOTS - 1u);
         for (uint32_t z = 0; z < MARK_SLOTS; ++z)
             if (z != keep) { ctrl->n_touched_bld[z] = 0u; ctrl->n_touched_room[z] = 0u; ctrl->n_touched_route[z] = 0u; ctrl->n_touched_route_big[z] = 0u; }
-    }
-    __syncthreads();
-    const uint32_t n_eff = n_eff_s;
-    if (tid < n_eff) {
-        const uint32_t s = t0 + tid;
-        d.hist[s + TE_BIAS] = win[(int)(s + TE_BIAS) - base_idx];
-        d.log_off[s + TE_BIAS + 1u] = off[tid];
-        if (s <= d.max_steps) d.records[s] = recs[tid];
     }
 }
 
