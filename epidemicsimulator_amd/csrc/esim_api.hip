@@ -23,7 +23,7 @@ struct esim_ctx_impl {
     bool own_stream = true;
     std::string err;
     // host copies needed for reset
-    std::vector<uint16_t> init_state;
+    std::vector<uint32_t> init_state;
     std::vector<uint32_t> init_log;       // distinct seeds
     size_t cnt_bytes = 0;
     uint32_t *cnt_base = nullptr;
@@ -274,11 +274,14 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     csr(R, N, [&](uint32_t i) { return room_fixed[i]; }, [&](uint32_t i) { return (fl[i] & FL_WORK_SCHOOL) != 0; }, room_off, room_idx);
 
     // ---- initial state: everyone Susceptible at home (citizen.rs:139-162), seeds Infected(0)
-    c->init_state.assign((size_t)N + 2, (uint16_t)TE_SUSCEPTIBLE);
+    c->init_state.resize(N);
+    for (uint32_t i = 0; i < N; ++i) c->init_state[i] = CW_MAKE(TE_SUSCEPTIBLE, (uint32_t)fl[i]);
     c->init_log.clear();
-    const uint16_t seed_te = (uint16_t)(TE_BIAS - (c->P.exposed_time + 1u));            // Infected(0) before step 1
-    for (uint32_t i = 0; i < pop->n_seeds; ++i)
-        if (c->init_state[pop->seeds[i]] != seed_te) { c->init_state[pop->seeds[i]] = seed_te; c->init_log.push_back(pop->seeds[i]); }
+    const uint32_t seed_te = TE_BIAS - (c->P.exposed_time + 1u);                        // Infected(0) before step 1
+    for (uint32_t i = 0; i < pop->n_seeds; ++i) {
+        const uint32_t sc = pop->seeds[i];
+        if (CW_TE(c->init_state[sc]) != seed_te) { c->init_state[sc] = CW_MAKE(seed_te, (uint32_t)fl[sc]); c->init_log.push_back(sc); }
+    }
 
     free_device(c);
     Dev &d = c->d;
@@ -286,8 +289,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     d.n = N; d.n_global = n_global; d.id_base = pop->citizen_id_base; d.n_bld = B; d.n_room = R;
     d.n_pt = (uint32_t)riders.size(); d.n_routes = n_routes; c->n_routes = n_routes;
     int rc;
-    if ((rc = dev_alloc(c, &d.state, (size_t)N + 2))) return rc;
-    if ((rc = dev_upload(c, &d.flags, fl.data(), N))) return rc;
+    if ((rc = dev_alloc(c, &d.cit, (size_t)N + 1))) return rc;
     if ((rc = dev_upload(c, &d.home, pop->home_building, N))) return rc;
     if ((rc = dev_upload(c, &d.work, pop->work_building, N))) return rc;
     if ((rc = dev_upload(c, &d.room, room_fixed.data(), N))) return rc;
@@ -376,7 +378,7 @@ extern "C" int esim_reset(esim_ctx *ctx)
     h.n_susceptible = d.n - n_seeds;
     h.log_len = n_seeds;
     HIP_TRY(c, hipMemcpy(d.ctrl, &h, sizeof h, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(d.state, c->init_state.data(), sizeof(uint16_t) * ((size_t)d.n + 2), hipMemcpyHostToDevice));
+    if (d.n) HIP_TRY(c, hipMemcpy(d.cit, c->init_state.data(), sizeof(uint32_t) * (size_t)d.n, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemset(c->cnt_base, 0, c->cnt_bytes));
     HIP_TRY(c, hipMemset(d.exp_step, 0, sizeof(uint32_t) * 2 * ((size_t)c->P.max_steps + 2)));
     HIP_TRY(c, hipMemset(d.records, 0, sizeof(esim_step_result) * ((size_t)c->P.max_steps + 1)));

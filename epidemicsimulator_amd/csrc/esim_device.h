@@ -2,18 +2,23 @@
 #pragma once
 #include <stdint.h>
 
-// ---- per-citizen dynamic state word (uint16, one per citizen, HBM) -------------------------
-// bits 0..12  te : TE_BIAS + (time step at which the citizen became Exposed(0)), or a sentinel.
-//                  DiseaseStatus (disease.rs:36-44) is a pure function of (current step - te):
-//                  the E/I timers of disease.rs:47-71 never have to be written back.
-// bit  13     bus_exposed : the exposure happened on public transport while a vaccination
-//                  programme was running (the citizen left citizens_eligible_for_vaccine,
-//                  simulator.rs:447-449)
+// ---- per-citizen word (uint32, one per citizen, HBM) ---------------------------------------
+// bits 31..19  te : TE_BIAS + (time step at which the citizen became Exposed(0)), or a sentinel.
+//                   DiseaseStatus (disease.rs:36-44) is a pure function of (current step - te):
+//                   the E/I timers of disease.rs:47-71 never have to be written back.
+// bit  18      bus_exposed : the exposure happened on public transport (the citizen leaves
+//                   citizens_eligible_for_vaccine, simulator.rs:447-449)
+// bits 7..0    static flags (below)
+// te sits in the most significant bits and Susceptible is the largest te, so "exposed at the earliest step
+// at which any draw succeeds; a building beats a bus within a step" is one atomicMin on this word.
 // Where a citizen stands (home / work / on a bus) is NOT per-citizen state: every citizen has
 // the same working hours (citizen.rs:154-155), so current_building_position and
 // on_public_transport are global functions of the clock and the lockdown history (Ctrl).
-#define ST_TE_MASK     0x1FFFu
-#define ST_BUS_EXPOSED 0x2000u
+#define CW_TE_SHIFT    19u
+#define CW_BUS_EXPOSED (1u << 18)
+#define CW_FLAGS       0xFFu
+#define CW_TE(w)       ((w) >> CW_TE_SHIFT)
+#define CW_MAKE(te, rest) (((te) << CW_TE_SHIFT) | (rest))
 #define TE_SUSCEPTIBLE 0x1FFFu
 #define TE_VACCINATED  0x1FFEu
 #define TE_RECOVERED   0x1FFDu
@@ -21,7 +26,7 @@
 #define TE_SLOTS       8192u
 #define ESIM_MAX_STEP  7600u         // TE_BIAS + step must stay below TE_RECOVERED
 
-// ---- per-citizen static flags (uint8) ------------------------------------------------------
+// ---- static flags (low byte of the citizen word) -------------------------------------------
 #define FL_USES_PT        0x01u      // ESIM_FLAG_USES_PUBLIC_TRANSPORT
 #define FL_MASK_COMPLIANT 0x02u      // ESIM_FLAG_MASK_COMPLIANT
 #define FL_SAME_AREA      0x04u      // area(work building) == area(home building)  (Q4, simulator.rs:324)
@@ -75,8 +80,7 @@ struct Dev {
     uint32_t n_global;          // citizens over all shards
     uint32_t id_base;           // global index of local citizen 0
     uint32_t n_bld, n_room, n_pt;
-    uint16_t *state;
-    const uint8_t  *flags;
+    uint32_t *cit;              // per-citizen word (te | bus_exposed | flags)
     const uint32_t *home, *work, *room;
     // static membership lists (the reference's occupant lists: output_area.rs:172-180,
     // simulator_builder.rs:1076,1100, building.rs:404-431)

@@ -128,8 +128,8 @@ __device__ __forceinline__ void infected_phase(const Dev &d, Ctrl *ctrl, const S
     const uint32_t i0 = d.log_off[lo < 0 ? 0 : lo], i1 = d.log_off[hi + 1];
     for (uint32_t i = i0 + vb * blockDim.x + threadIdx.x; i < i1; i += nvb * blockDim.x) {
         const uint32_t c = d.log[i];
-        if (status_of(d.state[c] & ST_TE_MASK, t, d.exposed_time, d.infected_time) != ESIM_INFECTED) continue;  // vaccinated since (Q10)
-        const uint32_t fl = d.flags[c];
+        const uint32_t fl = d.cit[c];
+        if (status_of(CW_TE(fl), t, d.exposed_time, d.infected_time) != ESIM_INFECTED) continue;  // vaccinated since (Q10)
         if (bus_dir && (fl & FL_USES_PT)) {                                  // simulator.rs:181-186
             const uint32_t r = d.route_of[c];
             if (atomicExch(&route_flag[r], 1u) == 0u) {
@@ -163,16 +163,14 @@ __device__ __forceinline__ uint64_t threshold(const Dev &d, uint32_t fl, uint32_
 }
 
 // Susceptible -> Exposed(0) (citizen.rs:244) exactly once per citizen even when several member
-// lists reach the same citizen concurrently: CAS on the 32-bit word holding the 16-bit state.
-__device__ __forceinline__ bool expose_once(const Dev &d, Ctrl *ctrl, uint32_t m, uint32_t new_state)
+// lists reach the same citizen concurrently: CAS on the citizen word.  new_te_bits = te (and bus bit) part.
+__device__ __forceinline__ bool expose_once(const Dev &d, Ctrl *ctrl, uint32_t m, uint32_t new_te_bits)
 {
-    uint32_t *w = reinterpret_cast<uint32_t *>(d.state + (m & ~1u));
-    const uint32_t sh = (m & 1u) * 16u;
+    uint32_t *w = d.cit + m;
     uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
-        if (((old >> sh) & ST_TE_MASK) != TE_SUSCEPTIBLE) return false;
-        const uint32_t nw = (old & ~(0xFFFFu << sh)) | (new_state << sh);
-        const uint32_t prev = atomicCAS(w, old, nw);
+        if (CW_TE(old) != TE_SUSCEPTIBLE) return false;
+        const uint32_t prev = atomicCAS(w, old, new_te_bits | (old & CW_FLAGS));
         if (prev == old) break;
         old = prev;
     }
@@ -214,10 +212,10 @@ __device__ __forceinline__ bool building_draws(const Dev &d, uint32_t c, uint32_
 
 // One candidate of one member list (simulator.rs:308-350 for one citizen_id of find_exposures), given its
 // state and flags.  kind 0: resident (home list), 1: worker (work list), 2: room participant (k draws).
-__device__ __forceinline__ void member_eval(const Dev &d, Ctrl *ctrl, uint32_t m, uint32_t st, uint32_t fl, uint32_t kind,
+__device__ __forceinline__ void member_eval(const Dev &d, Ctrl *ctrl, uint32_t m, uint32_t fl, uint32_t kind,
                                             uint32_t n, uint32_t k, uint32_t t, uint32_t mask, uint32_t at_work, uint32_t &n_exp)
 {
-    if ((st & ST_TE_MASK) != TE_SUSCEPTIBLE) return;                     // is_susceptible(), simulator.rs:337
+    if (CW_TE(fl) != TE_SUSCEPTIBLE) return;                             // is_susceptible(), simulator.rs:337
     const bool same = fl & FL_SAME_AREA;
     // area of current_building_position == area of this building?  simulator.rs:324
     if (kind == 0u) { if (at_work && (fl & FL_HAS_WORK) && !same) return; }
@@ -228,7 +226,7 @@ __device__ __forceinline__ void member_eval(const Dev &d, Ctrl *ctrl, uint32_t m
     bool hit = false;
     if (kind == 2u) { for (uint32_t j = 0; j < k && !hit; ++j) hit = esim_u53(seed, g, t, ESIM_SLOT_ROOM0 + j) < thr; }
     else hit = esim_u53(seed, g, t, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK) < thr;
-    if (hit && expose_once(d, ctrl, m, t + TE_BIAS)) n_exp++;            // Exposed(0), citizen.rs:244
+    if (hit && expose_once(d, ctrl, m, CW_MAKE(t + TE_BIAS, 0u))) n_exp++;   // Exposed(0), citizen.rs:244
 }
 
 // Members [lo, hi) of one list, walked by a group of 8 lanes (gl = lane in group): every lane takes up to four
@@ -239,16 +237,14 @@ __device__ __forceinline__ void member_list(const Dev &d, Ctrl *ctrl, const uint
                                             uint32_t &n_exp)
 {
     for (uint32_t base = lo + gl; base < hi; base += 32u) {
-        uint32_t m[4], st[4], fl[4];
+        uint32_t m[4], fl[4];
         bool ok[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const uint32_t q = base + 8u * u; ok[u] = q < hi; m[u] = ok[u] ? (idx ? idx[q] : q) : 0u; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) st[u] = ok[u] ? d.state[m[u]] : 0u;
+        for (int u = 0; u < 4; ++u) fl[u] = ok[u] ? d.cit[m[u]] : 0u;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) fl[u] = (ok[u] && (st[u] & ST_TE_MASK) == TE_SUSCEPTIBLE) ? d.flags[m[u]] : 0u;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (ok[u]) member_eval(d, ctrl, m[u], st[u], fl[u], kind, n, k, t, mask, at_work, n_exp);
+        for (int u = 0; u < 4; ++u) if (ok[u]) member_eval(d, ctrl, m[u], fl[u], kind, n, k, t, mask, at_work, n_exp);
     }
 }
 
@@ -257,11 +253,11 @@ __device__ __forceinline__ void member_list(const Dev &d, Ctrl *ctrl, const uint
 __device__ __forceinline__ void bus_draw(const Dev &d, Ctrl *ctrl, uint32_t c, uint32_t k, uint32_t t, uint32_t mask,
                                          uint32_t at_work)
 {
-    const uint32_t fl = d.flags[c];
+    const uint32_t fl = d.cit[c];
     if (building_draws(d, c, fl, t, mask, at_work)) return;              // the buildings got there first
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
     if (esim_u53(seed, d.id_base + c, t, ESIM_SLOT_BUS) < threshold(d, fl, mask, k)) {
-        if (expose_once(d, ctrl, c, (t + TE_BIAS) | ST_BUS_EXPOSED)) {
+        if (expose_once(d, ctrl, c, CW_MAKE(t + TE_BIAS, CW_BUS_EXPOSED))) {
             atomicAdd(&d.exp_step[2u * t + 1u], 1u);
             if (ctrl->have_elig) atomicSub(&ctrl->elig_count, 1u);       // simulator.rs:447-449 (a Susceptible is eligible)
         }
@@ -318,8 +314,8 @@ __device__ __forceinline__ void expose_phase(const Dev &d, Ctrl *ctrl, const Ste
         bool inf = false;
         if (lane < s) {
             c = d.route_riders[off + lane];
-            st = d.state[c];
-            inf = status_of(st & ST_TE_MASK, t, d.exposed_time, d.infected_time) == ESIM_INFECTED;
+            st = d.cit[c];
+            inf = status_of(CW_TE(st), t, d.exposed_time, d.infected_time) == ESIM_INFECTED;
             key = philox4x32_10(d.id_base + c, t, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
         }
         uint32_t rank = 0;
@@ -334,7 +330,7 @@ __device__ __forceinline__ void expose_phase(const Dev &d, Ctrl *ctrl, const Ste
             const bool ij = __shfl((int)inf, j, 64);
             k += ij && bj == bus;
         }
-        if (lane < s && k && (st & ST_TE_MASK) == TE_SUSCEPTIBLE) bus_draw(d, ctrl, c, k, t, mask, at_work);
+        if (lane < s && k && CW_TE(st) == TE_SUSCEPTIBLE) bus_draw(d, ctrl, c, k, t, mask, at_work);
     }
     // routes of > 64 riders (rare: a very large Output Area): rank by counting through global scratch
     const uint32_t nbig = ld(&ctrl->n_touched_route_big[p]);
@@ -343,7 +339,7 @@ __device__ __forceinline__ void expose_phase(const Dev &d, Ctrl *ctrl, const Ste
         const uint32_t off = d.route_off[r], s = d.route_off[r + 1] - off;
         for (uint32_t i = threadIdx.x; i < s; i += blockDim.x) {
             const uint32_t c = d.route_riders[off + i];
-            const bool inf = status_of(d.state[c] & ST_TE_MASK, t, d.exposed_time, d.infected_time) == ESIM_INFECTED;
+            const bool inf = status_of(CW_TE(d.cit[c]), t, d.exposed_time, d.infected_time) == ESIM_INFECTED;
             d.bus_key[off + i] = philox4x32_10(d.id_base + c, t, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
             d.bus_flag[off + i] = inf ? 1u : 0u;
             d.bus_cnt[off + i] = 0u;
@@ -364,7 +360,7 @@ __device__ __forceinline__ void expose_phase(const Dev &d, Ctrl *ctrl, const Ste
         for (uint32_t i = threadIdx.x; i < s; i += blockDim.x) {
             const uint32_t c = d.route_riders[off + i];
             const uint32_t k = __hip_atomic_load(&d.bus_cnt[off + d.bus_idx[off + i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (k && (d.state[c] & ST_TE_MASK) == TE_SUSCEPTIBLE) bus_draw(d, ctrl, c, k, t, mask, at_work);
+            if (k && CW_TE(d.cit[c]) == TE_SUSCEPTIBLE) bus_draw(d, ctrl, c, k, t, mask, at_work);
         }
         __syncthreads();
     }
@@ -429,10 +425,10 @@ __device__ __forceinline__ uint32_t vacc_candidate(const Dev &d, uint32_t i, uin
 // and vaccination never remove anybody (Q10).  All of that is recoverable from the state word.
 __device__ __forceinline__ bool eligible(uint32_t st, uint32_t trigger_step)
 {
-    const uint32_t te = st & ST_TE_MASK;
+    const uint32_t te = CW_TE(st);
     if (te == TE_SUSCEPTIBLE || te == TE_VACCINATED) return true;        // only eligible citizens are ever vaccinated
     if (te >= TE_RECOVERED) return false;
-    return te > trigger_step + TE_BIAS && !(st & ST_BUS_EXPOSED);
+    return te > trigger_step + TE_BIAS && !(st & CW_BUS_EXPOSED);
 }
 
 // Liveness of the first VACC_BATCH vaccination candidates, owner computes (sharded runs).
@@ -454,7 +450,7 @@ __global__ __launch_bounds__(TPB) void k_pack_b(Dev d)
     if (i < VACC_BATCH) {
         const uint32_t j = vacc_candidate(d, i, t);
         bool live = false;
-        if ((ctrl->have_elig || trig) && j >= d.id_base && j - d.id_base < d.n) live = eligible(d.state[j - d.id_base], tstep);
+        if ((ctrl->have_elig || trig) && j >= d.id_base && j - d.id_base < d.n) live = eligible(d.cit[j - d.id_base], tstep);
         const unsigned long long m = __ballot(live);
         if ((threadIdx.x & 63u) == 0) { d.xb[XB_HEADER + (i >> 5)] = (uint32_t)m; d.xb[XB_HEADER + (i >> 5) + 1] = (uint32_t)(m >> 32); }
     }
@@ -641,13 +637,13 @@ __global__ __launch_bounds__(FIN_TPB) void k_batch_finish(Dev d, uint32_t t0, ui
 // Vaccination bookkeeping for one citizen set to Vaccinated (simulator.rs:551).
 __device__ __forceinline__ void vaccinate(const Dev &d, Ctrl *ctrl, uint32_t c)
 {
-    const uint32_t st = d.state[c], te = st & ST_TE_MASK;
+    const uint32_t st = d.cit[c], te = CW_TE(st);
     if (te == TE_VACCINATED) return;                                     // chosen again: ids are never removed (Q10)
     if (te == TE_SUSCEPTIBLE) atomicSub(&ctrl->n_susceptible, 1u);
     else if (te == TE_RECOVERED) atomicSub(&ctrl->n_recovered_sentinel, 1u);
     else atomicSub(&d.hist[te], 1u);                                     // an Exposed/Infected/Recovered citizen is relabelled
     atomicAdd(&ctrl->n_vaccinated, 1u);
-    d.state[c] = (uint16_t)((st & ~ST_TE_MASK) | TE_VACCINATED);
+    d.cit[c] = CW_MAKE(TE_VACCINATED, st & (CW_BUS_EXPOSED | CW_FLAGS));
 }
 
 // ---------------------------------------------------------------------------------- k_finish
@@ -704,7 +700,7 @@ __device__ __forceinline__ void finish_phase(const Dev &d, Ctrl *ctrl, int shard
         if (elig_count <= d.vaccination_rate) {
             // choose_multiple hands back the whole set (simulator.rs:525-527)
             for (uint32_t c = tid; c < d.n; c += FIN_TPB)
-                if (eligible(d.state[c], tstep)) vaccinate(d, ctrl, c);
+                if (eligible(d.cit[c], tstep)) vaccinate(d, ctrl, c);
             vacc_now = elig_count;
         } else {
             const uint32_t k = d.vaccination_rate;
@@ -718,7 +714,7 @@ __device__ __forceinline__ void finish_phase(const Dev &d, Ctrl *ctrl, int shard
                     const uint32_t i = base + tid * 4u + q;
                     j[q] = vacc_candidate(d, i, t);
                     if (sharded) live[q] = (d.xb[XB_HEADER + ((i - base) >> 5)] >> ((i - base) & 31u)) & 1u;
-                    else live[q] = eligible(d.state[j[q]], tstep);
+                    else live[q] = eligible(d.cit[j[q]], tstep);
                     slot[q] = 0;
                     if (live[q]) {
                         uint32_t sl = (j[q] * 2654435761u) >> 18;        // 14 bits
@@ -855,7 +851,7 @@ __global__ __launch_bounds__(TPB) void k_decode_state(Dev d, uint8_t *status, ui
     const Ctrl *ctrl = d.ctrl;
     const uint32_t t = ctrl->t - 1u;             // last completed step
     for (uint32_t c = blockIdx.x * TPB + threadIdx.x; c < d.n; c += gridDim.x * TPB) {
-        const uint32_t st = d.state[c], te = st & ST_TE_MASK, fl = d.flags[c];
+        const uint32_t st = d.cit[c], te = CW_TE(st), fl = st & CW_FLAGS;
         const uint32_t cls = status_of(te, t, d.exposed_time, d.infected_time);
         uint32_t tm = 0;
         if (te < TE_RECOVERED) {
