@@ -41,6 +41,9 @@ struct esim_ctx_impl {
     std::vector<hipEvent_t> kev;       // two per timed step: before k_infected, after k_finish
     size_t kev_used = 0;
     uint32_t grid_citizens = 1, grid_infected = 1, grid_expose = 1;
+    bool time_parallel = true;         // draw all steps of a chunk in one pass when its marks fit the hash map
+    hipEvent_t cev[2] = { nullptr, nullptr }; double chunk_ms = 0; uint64_t chunk_steps = 0, chunk_count = 0;
+    uint32_t grid_chunk = 1024;
     bool pipeline = true;              // run chunks of steps as one kernel per step while no vaccination programme runs
     std::vector<hipEvent_t> pkev; size_t pkev_used = 0; uint64_t pipe_steps = 0;   // sampled k_pipe launches
     uint32_t small_max = 128;          // infected-slice length up to which the persistent single-workgroup kernel runs a step
@@ -179,6 +182,7 @@ extern "C" void esim_destroy(esim_ctx *ctx)
     for (auto &ev : c->kev) (void)hipEventDestroy(ev);
     for (auto &ev : c->sev) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->pkev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->cev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -252,7 +256,8 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     const uint32_t n_routes = (uint32_t)route_off.size();
     route_off.push_back((uint32_t)pairs.size());
     bool any_big = false;
-    for (uint32_t r = 0; r < n_routes; ++r) any_big |= route_off[r + 1] - route_off[r] > 64;
+    uint32_t max_route = 0;
+    for (uint32_t r = 0; r < n_routes; ++r) { any_big |= route_off[r + 1] - route_off[r] > 64; max_route = std::max(max_route, route_off[r + 1] - route_off[r]); }
     { std::vector<std::pair<uint64_t, uint32_t>>().swap(pairs); }
 
     // ---- static member lists (the occupant lists the reference keeps per building:
@@ -288,6 +293,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     std::memset(&d, 0, sizeof d);
     d.n = N; d.n_global = n_global; d.id_base = pop->citizen_id_base; d.n_bld = B; d.n_room = R;
     d.n_pt = (uint32_t)riders.size(); d.n_routes = n_routes; c->n_routes = n_routes;
+    d.max_route = max_route;
     int rc;
     if ((rc = dev_alloc(c, &d.cit, (size_t)N + 1))) return rc;
     if ((rc = dev_upload(c, &d.home, pop->home_building, N))) return rc;
@@ -309,6 +315,21 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     c->cnt_bytes = sizeof(uint32_t) * MARK_SLOTS * per_parity;
     if ((rc = dev_alloc(c, &d.exp_step, 2 * ((size_t)c->P.max_steps + 2)))) return rc;
     if ((rc = dev_alloc(c, &d.dec, FREE_MAX + 1))) return rc;
+    // hash map of the time-parallel chunks: room for ~2 marks per (Infected, step) pair at < 1/2 load
+    {
+        uint32_t cap = 1u << 20;
+        while (cap < (1u << 26) && cap < N / 4u) cap <<= 1;
+        if (const char *e = std::getenv("ESIM_HASH_LOG2")) cap = 1u << std::min(28, std::max(4, std::atoi(e)));
+        d.hcap = cap;
+        if ((rc = dev_alloc(c, &d.hkey, cap))) return rc;
+        if ((rc = dev_alloc(c, &d.hcnt, cap))) return rc;
+        if ((rc = dev_alloc(c, &d.hitems, cap))) return rc;
+        if ((rc = dev_alloc(c, &d.newexp, (size_t)N + 1))) return rc;
+        if ((rc = dev_alloc(c, &d.cursor, FREE_MAX))) return rc;
+        HIP_TRY(c, hipMemset(d.hkey, 0xFF, sizeof(unsigned long long) * cap));
+        HIP_TRY(c, hipMemset(d.hcnt, 0, sizeof(uint32_t) * cap));
+        HIP_TRY(c, hipMemset(d.cursor, 0, sizeof(uint32_t) * FREE_MAX));
+    }
     for (int p = 0; p < (int)MARK_SLOTS; ++p) {
         uint32_t *base = cnt + p * per_parity;
         d.cnt_bld[p] = base; d.cnt_room[p] = base + B; d.route_flag[p] = base + B + R;
@@ -396,6 +417,7 @@ extern "C" int esim_reset(esim_ctx *ctx)
     c->kev_used = 0;
     c->small_ms = 0; c->small_steps = 0;
     c->pkev_used = 0; c->pipe_steps = 0;
+    c->chunk_ms = 0; c->chunk_steps = 0; c->chunk_count = 0;
     return ESIM_OK;
 }
 
@@ -551,7 +573,7 @@ int run_sequential(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, ui
 int run_chunk(esim_ctx_impl *c, uint32_t n_ahead, uint32_t *executed, Ctrl *state_before)
 {
     Dev &d = c->d;
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(128), 0, c->stream, d, n_ahead);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(128), 0, c->stream, d, n_ahead, c->time_parallel ? 1 : 0);
     Ctrl h;
     HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -560,6 +582,21 @@ int run_chunk(esim_ctx_impl *c, uint32_t n_ahead, uint32_t *executed, Ctrl *stat
     const uint32_t n = h.chunk_ok, t0 = h.t;
     *executed = 0;
     if (n == 0) return ESIM_OK;
+    if (h.chunk_parallel) {
+        // every step of the chunk in one pass: marks of all steps, draws of all (item, step) pairs, then the books
+        const bool tk = c->kernel_timing;
+        if (tk) { if (!c->cev[0]) { (void)hipEventCreate(&c->cev[0]); (void)hipEventCreate(&c->cev[1]); } HIP_TRY(c, hipEventRecord(c->cev[0], c->stream)); }
+        hipLaunchKernelGGL(k_chunk_mark, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d, t0, n);
+        hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d, t0, n);
+        hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);
+        hipLaunchKernelGGL(k_batch_finish, dim3(1), dim3(FIN_TPB), 0, c->stream, d, t0, n);
+        hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d, t0);
+        if (tk) { HIP_TRY(c, hipEventRecord(c->cev[1], c->stream)); HIP_TRY(c, hipEventSynchronize(c->cev[1])); float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->cev[0], c->cev[1])); c->chunk_ms += ms; }
+        HIP_TRY(c, hipGetLastError());
+        c->chunk_steps += n; c->chunk_count++;
+        *executed = n;
+        return ESIM_OK;
+    }
     hipLaunchKernelGGL(k_infected_dec, dim3(c->grid_infected), dim3(TPB), 0, c->stream, d, t0, 0u);
     for (uint32_t j = 0; j < n; ++j) {
         bool tk = c->kernel_timing && ((t0 + j) % c->kernel_timing_stride) == 0;
@@ -685,7 +722,19 @@ extern "C" int esim_set_pipeline(esim_ctx *ctx, int enable)
 {
     esim_ctx_impl *c = CTX(ctx);
     if (!c) return ESIM_EINVAL;
-    c->pipeline = enable != 0;
+    c->pipeline = enable != 0;            // 0: sequential steps only
+    c->time_parallel = enable >= 2;       // 1: one kernel per step (k_pipe); 2: all steps of a chunk in one pass
+    return ESIM_OK;
+}
+
+extern "C" int esim_chunk_timing(esim_ctx *ctx, double *total_ms, uint64_t *steps, uint64_t *chunks)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c) return ESIM_EINVAL;
+    if (total_ms) *total_ms = c->chunk_ms;
+    if (steps) *steps = c->chunk_steps;
+    if (chunks) *chunks = c->chunk_count;
+    c->chunk_ms = 0; c->chunk_steps = 0; c->chunk_count = 0;
     return ESIM_OK;
 }
 

@@ -65,7 +65,11 @@ struct Ctrl {
     uint32_t free_base;         // first step of the current free-running batch (decoupled sharded mode)
     uint32_t small_done;        // steps executed by the last k_small launch
     uint32_t chunk_ok;          // steps of the current chunk that may run pipelined (k_decide)
-    uint32_t pad[6];
+    uint32_t chunk_parallel;    // 1: the chunk's marks fit the hash map, all its steps can be drawn in one pass
+    uint32_t chunk_pairs;       // (Infected citizen, step) pairs of the chunk on this shard (k_future)
+    uint32_t n_items;           // marked (building | room | route, step) entries of the chunk
+    uint32_t n_newexp;          // citizens exposed in the chunk
+    uint32_t pad[2];
 };
 
 // What is in force during one step of a pipelined chunk (k_decide fills dec[0..chunk_ok]).
@@ -96,6 +100,14 @@ struct Dev {
     uint32_t *route_flag[MARK_SLOTS];    // [n_routes]
     uint32_t *exp_step;         // [2 * (max_steps + 2)] successful exposures per step: [2t] buildings, [2t+1] buses
     struct Decision *dec;       // [FREE_MAX + 1]
+    // time-parallel chunks: infected per (building | room | route, step of the chunk) in an open-addressing hash map
+    unsigned long long *hkey;   // [hcap] (slot id << 8 | step offset), HKEY_EMPTY when free
+    uint32_t *hcnt;             // [hcap]
+    uint32_t hcap;              // power of two
+    uint32_t *hitems;           // [hcap / 2] occupied entries of the chunk
+    uint32_t *newexp;           // [n] citizens exposed in the chunk
+    uint32_t *cursor;           // [FREE_MAX] per-step write cursors into the log
+    uint32_t max_route;         // riders of the largest route
     uint32_t *hist;             // [TE_SLOTS] citizens per exposure time (census without a pass over citizens)
     uint32_t *log;              // exposure log: citizen ids in order of exposure step
     uint32_t *log_off;          // [TE_SLOTS + 1] first log entry whose te >= k
@@ -127,3 +139,5 @@ struct Dev {
 #define XB_HEADER 8u
 // exchange buffer F: Infected census of the next FREE_MAX steps (decoupled sharded mode)
 #define FREE_MAX 96u
+#define HKEY_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define CHUNK_ROUTE_MAX 2048u      // routes up to this many riders are ranked in LDS by the time-parallel pass

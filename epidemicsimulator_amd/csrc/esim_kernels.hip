@@ -489,15 +489,20 @@ __global__ __launch_bounds__(FIN_TPB) void k_future(Dev d, uint32_t n_ahead)
     { const int k = base_idx + (int)tid; win[tid] = (k >= 0 && k < (int)TE_SLOTS) ? d.hist[k] : 0u; }
     __syncthreads();
     block_scan_1024(win, wtmp);                                            // win[i] = sum of hist[base_idx .. base_idx + i]
+    __shared__ uint32_t pairs;
+    if (tid == 0) pairs = 0u;
+    __syncthreads();
     if (tid < n_ahead) {
         // Infected window of step t0 + tid: entries [tid, tid + it] of the loaded range
         const uint32_t hi = win[tid + (uint32_t)it], lo = tid ? win[tid - 1u] : 0u;
         d.xf[tid] = hi - lo;
+        atomicAdd(&pairs, hi - lo);
     }
-    if (tid == 0) ctrl->free_base = t0;
+    __syncthreads();
+    if (tid == 0) { ctrl->free_base = t0; ctrl->chunk_pairs = pairs; }
 }
 
-__global__ __launch_bounds__(128) void k_decide(Dev d, uint32_t n_ahead)
+__global__ __launch_bounds__(128) void k_decide(Dev d, uint32_t n_ahead, int allow_parallel)
 {
     __shared__ double xs[FREE_MAX];
     __shared__ Decision ds[FREE_MAX + 1];
@@ -536,7 +541,12 @@ __global__ __launch_bounds__(128) void k_decide(Dev d, uint32_t n_ahead)
         ds[n_ok] = q;                                                         // what is in force after the chunk
         n_ok_s = n_ok;
         ctrl->chunk_ok = n_ok;
+        // every (Infected, step) pair marks at most a building and a room: keep the map under half full
+        ctrl->chunk_parallel = (allow_parallel && d.hcap && d.max_route <= CHUNK_ROUTE_MAX &&
+                                (unsigned long long)ctrl->chunk_pairs * 4ull <= (unsigned long long)d.hcap) ? 1u : 0u;
+        ctrl->n_items = 0u; ctrl->n_newexp = 0u;
     }
+    if (threadIdx.x < FREE_MAX) d.cursor[threadIdx.x] = 0u;
     __syncthreads();
     if (threadIdx.x <= n_ok_s) d.dec[threadIdx.x] = ds[threadIdx.x];
 }
@@ -563,6 +573,217 @@ __global__ __launch_bounds__(TPB) void k_pipe(Dev d, uint32_t t, uint32_t j, uin
         expose_phase(d, ctrl, env_from_dec(d, t, j), blockIdx.x, n_expose);
     } else if (mark_next) {
         infected_phase(d, ctrl, env_from_dec(d, t + 1u, j + 1u), blockIdx.x - n_expose, gridDim.x - n_expose);
+    }
+}
+
+// ------------------------------------------------------------------------- time-parallel chunk
+// Inside a chunk nothing a draw depends on changes: who is Infected and where (known ahead), the mask
+// status, the Philox counters.  A citizen's exposure step is therefore simply the EARLIEST step at which any of
+// its draws succeeds (later draws would have been skipped by `is_susceptible()`, simulator.rs:337), and within a
+// step a building exposure precedes a bus exposure (simulator.rs:268-401).  With the exposure step in the top
+// bits of the citizen word and the bus bit right below, that is one atomicMin per successful draw -- so all
+// steps of the chunk are drawn in ONE pass over the (marked item, step) pairs.
+__device__ __forceinline__ uint32_t hash64(unsigned long long k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (uint32_t)k;
+}
+
+__device__ __forceinline__ void mark_add(const Dev &d, Ctrl *ctrl, unsigned long long key)
+{
+    uint32_t h = hash64(key) & (d.hcap - 1u);
+    for (uint32_t probe = 0; probe < d.hcap; ++probe) {
+        const unsigned long long old = atomicCAS(&d.hkey[h], HKEY_EMPTY, key);
+        if (old == HKEY_EMPTY) { atomicAdd(&d.hcnt[h], 1u); append(d.hitems, &ctrl->n_items, h); return; }
+        if (old == key) { atomicAdd(&d.hcnt[h], 1u); return; }
+        h = (h + 1u) & (d.hcap - 1u);
+    }
+    ctrl->error = (uint32_t)(-ESIM_ERANGE);
+}
+
+__device__ __forceinline__ uint32_t mark_get(const Dev &d, unsigned long long key)
+{
+    uint32_t h = hash64(key) & (d.hcap - 1u);
+    for (uint32_t probe = 0; probe < d.hcap; ++probe) {
+        const unsigned long long k = d.hkey[h];
+        if (k == key) return d.hcnt[h];
+        if (k == HKEY_EMPTY) return 0u;
+        h = (h + 1u) & (d.hcap - 1u);
+    }
+    return 0u;
+}
+
+// generate_exposures (simulator.rs:181-198) for every step of the chunk: one thread per (log entry, step).
+__global__ __launch_bounds__(TPB) void k_chunk_mark(Dev d, uint32_t t0, uint32_t n)
+{
+    Ctrl *ctrl = d.ctrl;
+    {
+        // the marks of step t0 - 1 (made by a sequential or pipelined step) would have been cleared by the exposure
+        // pass of step t0; this chunk has none, so clear them here
+        const uint32_t q = (t0 + MARK_SLOTS - 1u) & (MARK_SLOTS - 1u);
+        const uint32_t tid = blockIdx.x * TPB + threadIdx.x, nth = gridDim.x * TPB;
+        const uint32_t ob = ctrl->n_touched_bld[q], orr = ctrl->n_touched_room[q], ort = ctrl->n_touched_route[q], orb = ctrl->n_touched_route_big[q];
+        for (uint32_t i = tid; i < ob; i += nth) d.cnt_bld[q][d.touched_bld[q][i]] = 0u;
+        for (uint32_t i = tid; i < orr; i += nth) d.cnt_room[q][d.touched_room[q][i]] = 0u;
+        for (uint32_t i = tid; i < ort; i += nth) d.route_flag[q][d.touched_route[q][i]] = 0u;
+        for (uint32_t i = tid; i < orb; i += nth) d.route_flag[q][d.touched_route_big[q][i]] = 0u;
+    }
+    const int lo_te = (int)(t0 + TE_BIAS) - (int)d.exposed_time - 1 - (int)d.infected_time;     // Infected in step t0
+    const int hi_te = (int)(t0 + n - 1u + TE_BIAS) - (int)d.exposed_time - 1;                    // Infected in step t0 + n - 1
+    if (hi_te < 0) return;
+    const uint32_t i0 = d.log_off[lo_te < 0 ? 0 : lo_te], i1 = d.log_off[hi_te + 1];
+    const unsigned long long total = (unsigned long long)(i1 - i0) * n;
+    for (unsigned long long p = (unsigned long long)blockIdx.x * TPB + threadIdx.x; p < total; p += (unsigned long long)gridDim.x * TPB) {
+        const uint32_t e = i0 + (uint32_t)(p / n), j = (uint32_t)(p % n), s = t0 + j;
+        const uint32_t c = d.log[e];
+        const uint32_t w = d.cit[c];
+        if (status_of(CW_TE(w), s, d.exposed_time, d.infected_time) != ESIM_INFECTED) continue;
+        const Decision q = d.dec[j];
+        if (q.bus_dir && (w & FL_USES_PT)) {                                  // simulator.rs:181-186
+            mark_add(d, ctrl, ((unsigned long long)(d.n_bld + d.n_room + d.route_of[c]) << 8) | j);
+        } else {                                                              // :187-198
+            const bool atw = q.at_work && (w & FL_HAS_WORK);
+            mark_add(d, ctrl, ((unsigned long long)(atw ? d.work[c] : d.home[c]) << 8) | j);
+            if (atw && (w & FL_WORK_SCHOOL)) mark_add(d, ctrl, ((unsigned long long)(d.n_bld + d.room[c]) << 8) | j);
+        }
+    }
+}
+
+// A successful draw of citizen m in step s (bus: on public transport).
+__device__ __forceinline__ void expose_min(const Dev &d, Ctrl *ctrl, uint32_t m, uint32_t w, uint32_t s, uint32_t bus)
+{
+    const uint32_t cand = CW_MAKE(s + TE_BIAS, bus | (w & CW_FLAGS));
+    const uint32_t prev = atomicMin(&d.cit[m], cand);
+    if (cand < prev && CW_TE(prev) == TE_SUSCEPTIBLE) append(d.newexp, &ctrl->n_newexp, m);   // first exposure in this chunk
+}
+
+__device__ __forceinline__ void member_list_chunk(const Dev &d, Ctrl *ctrl, const uint32_t *idx, uint32_t lo, uint32_t hi, uint32_t gl,
+                                                  uint32_t kind, uint32_t n, uint32_t k, uint32_t s, uint32_t mask, uint32_t at_work)
+{
+    const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
+    for (uint32_t base = lo + gl; base < hi; base += 32u) {
+        uint32_t m[4], w[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint32_t q = base + 8u * u; ok[u] = q < hi; m[u] = ok[u] ? (idx ? idx[q] : q) : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = ok[u] ? d.cit[m[u]] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            const uint32_t te = CW_TE(w[u]), fl = w[u];
+            // Susceptible when this list is walked in step s: never exposed, or so far only exposed by something
+            // that comes later (a later step, or a bus of this step) -- that exposure may be undercut
+            if (w[u] <= CW_MAKE(s + TE_BIAS, fl & CW_FLAGS) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE)) continue;
+            const bool same = fl & FL_SAME_AREA;
+            if (kind == 0u) { if (at_work && (fl & FL_HAS_WORK) && !same) continue; }        // simulator.rs:324
+            else if (!at_work && !same) continue;
+            const uint64_t thr = threshold(d, fl, mask, n);
+            const uint32_t g = d.id_base + m[u];
+            bool hit = false;
+            if (kind == 2u) { for (uint32_t j = 0; j < k && !hit; ++j) hit = esim_u53(seed, g, s, ESIM_SLOT_ROOM0 + j) < thr; }
+            else hit = esim_u53(seed, g, s, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK) < thr;
+            if (hit) expose_min(d, ctrl, m[u], w[u], s, 0u);
+        }
+    }
+}
+
+// apply_exposures (simulator.rs:262-405) for every marked (item, step) of the chunk.
+__global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t t0, uint32_t n)
+{
+    __shared__ uint32_t s_key[CHUNK_ROUTE_MAX];
+    __shared__ uint16_t s_bus[CHUNK_ROUTE_MAX];
+    __shared__ uint8_t s_inf[CHUNK_ROUTE_MAX];
+    __shared__ uint32_t s_cnt[CHUNK_ROUTE_MAX + 1];
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t n_items = ld(&ctrl->n_items);
+    const uint32_t lane = threadIdx.x & 63u, grp = lane >> 3, gl = lane & 7u;
+    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    const uint32_t route_base = d.n_bld + d.n_room;
+    // (1) buildings and school rooms: groups of 8 lanes
+    for (uint32_t base = wave * 8u; base < n_items; base += n_waves * 8u) {
+        const uint32_t it = base + grp;
+        if (it >= n_items) continue;
+        const uint32_t h = d.hitems[it];
+        const unsigned long long key = d.hkey[h];
+        const uint32_t id = (uint32_t)(key >> 8), j = (uint32_t)(key & 0xFFu), s = t0 + j;
+        if (id >= route_base || j >= n) continue;
+        const Decision q = d.dec[j];
+        const uint32_t cnt = d.hcnt[h];
+        if (id < d.n_bld) {
+            if (d.bld_type[id] == ESIM_SCHOOL) continue;                       // School::find_exposures works per room
+            member_list_chunk(d, ctrl, d.res_idx, d.res_off[id], d.res_off[id + 1], gl, 0u, cnt, 0u, s, q.mask, q.at_work);
+            member_list_chunk(d, ctrl, d.wrk_idx, d.wrk_off[id], d.wrk_off[id + 1], gl, 1u, cnt, 0u, s, q.mask, q.at_work);
+        } else {
+            const uint32_t r = id - d.n_bld;
+            const uint32_t nsch = mark_get(d, ((unsigned long long)d.room_bld[r] << 8) | j);   // infected in the whole school
+            member_list_chunk(d, ctrl, d.room_idx, d.room_off[r], d.room_off[r + 1], gl, 2u, nsch, cnt, s, q.mask, q.at_work);
+        }
+    }
+    // (2) routes: one workgroup per (route, step); rank by (Philox key, id) through LDS, buses are runs of
+    // bus_capacity ranks (simulator.rs:362-388)
+    const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const uint32_t h = d.hitems[it];
+        const unsigned long long key = d.hkey[h];
+        const uint32_t id = (uint32_t)(key >> 8), j = (uint32_t)(key & 0xFFu), s = t0 + j;
+        if (id < route_base || j >= n) continue;                              // block-uniform
+        const uint32_t r = id - route_base;
+        const uint32_t off = d.route_off[r], sz = d.route_off[r + 1] - off;
+        const uint32_t mask = d.dec[j].mask;
+        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
+            const uint32_t c = d.route_riders[off + i];
+            s_key[i] = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
+            s_inf[i] = status_of(CW_TE(d.cit[c]), s, d.exposed_time, d.infected_time) == ESIM_INFECTED ? 1 : 0;
+        }
+        for (uint32_t i = threadIdx.x; i < sz / d.bus_capacity + 1u; i += TPB) s_cnt[i] = 0u;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
+            const uint32_t ki = s_key[i];
+            uint32_t rank = 0;
+            for (uint32_t q = 0; q < sz; ++q) { const uint32_t kq = s_key[q]; rank += kq < ki || (kq == ki && q < i); }
+            const uint32_t bus = rank / d.bus_capacity;
+            s_bus[i] = (uint16_t)bus;
+            if (s_inf[i]) atomicAdd(&s_cnt[bus], 1u);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
+            const uint32_t k = s_cnt[s_bus[i]];
+            if (!k) continue;
+            const uint32_t c = d.route_riders[off + i];
+            const uint32_t w = d.cit[c], te = CW_TE(w);
+            if (w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_FLAGS)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE)) continue;   // exposed before this bus
+            if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < threshold(d, w, mask, k)) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
+        }
+        __syncthreads();
+    }
+}
+
+// Exposures per step (statistics.rs:181) from the final citizen words.
+__global__ __launch_bounds__(TPB) void k_chunk_count(Dev d)
+{
+    const uint32_t n_new = ld(&d.ctrl->n_newexp);
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_new; i += gridDim.x * TPB) {
+        const uint32_t w = d.cit[d.newexp[i]];
+        const uint32_t s = CW_TE(w) - TE_BIAS;
+        atomicAdd(&d.exp_step[2u * s + ((w & CW_BUS_EXPOSED) ? 1u : 0u)], 1u);
+    }
+}
+
+// The chunk's exposures enter the log grouped by step (after k_batch_finish wrote the offsets); the hash map is
+// emptied for the next chunk.
+__global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d, uint32_t t0)
+{
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t n_new = ld(&ctrl->n_newexp), n_items = ld(&ctrl->n_items);
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_new; i += gridDim.x * TPB) {
+        const uint32_t m = d.newexp[i];
+        const uint32_t te = CW_TE(d.cit[m]);
+        d.log[d.log_off[te] + atomicAdd(&d.cursor[te - TE_BIAS - t0], 1u)] = m;
+    }
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_items; i += gridDim.x * TPB) {
+        const uint32_t h = d.hitems[i];
+        d.hkey[h] = HKEY_EMPTY; d.hcnt[h] = 0u;
     }
 }
 
@@ -623,6 +844,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_batch_finish(Dev d, uint32_t t0, ui
     }
     if (tid == 0) {
         ctrl->n_susceptible = S0 - (P[top0 + (int)n_eff] - P[top0]);
+        ctrl->log_len = run0 + (P[top0 + (int)n_eff] - P[top0]);
         ctrl->t = t0 + n_eff; ctrl->steps_done = t0 + n_eff - 1u;
         if (n_eff < n) ctrl->finished = 1u;
         ctrl->lockdown = d.dec[n_eff].lockdown; ctrl->mask = d.dec[n_eff].mask;

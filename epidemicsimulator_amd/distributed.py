@@ -207,9 +207,14 @@ class ShardedSimulator:
     def set_small_step_limit(self, max_infected):
         _lib.check(self.lib.esim_set_small_step_limit(self._ctx, int(max_infected)), self._ctx)
 
-    def set_pipeline(self, on):
-        """Pipelined chunks (one kernel per step while no vaccination programme runs) on/off."""
-        _lib.check(self.lib.esim_set_pipeline(self._ctx, int(bool(on))), self._ctx)
+    def set_pipeline(self, level):
+        """0: sequential steps only; 1: chunks as one kernel per step; 2 (default): time-parallel chunks."""
+        _lib.check(self.lib.esim_set_pipeline(self._ctx, int(level)), self._ctx)
+
+    def chunk_timing(self):
+        ms, ns, nc = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self.lib.esim_chunk_timing(self._ctx, C.byref(ms), C.byref(ns), C.byref(nc)), self._ctx)
+        return {"chunk_ms": ms.value, "steps": ns.value, "chunks": nc.value}
 
     def pipeline_timing(self):
         ms, nt, nr = C.c_double(0), C.c_uint64(0), C.c_uint64(0)

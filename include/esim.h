@@ -155,10 +155,15 @@ int  esim_exchange_buffer(esim_ctx *ctx, int which /* 0 = A, 1 = B, 2 = F */, vo
  *   esim_run_free(k, &done) -- runs min(k, steps before the one that would start vaccinating) whole steps
  *                              with no exchange; records hold THIS shard's census; done < k means the next
  *                              step must be a coupled one (esim_step_begin / _exposures / _finish).
- * esim_set_pipeline(ctx, 0) makes esim_run / esim_step use sequential steps only. */
+ * esim_set_pipeline(ctx, level): 0 = sequential steps only; 1 = chunks run as one kernel per step (k_pipe);
+ * 2 (default) = additionally, when the chunk's marks fit the hash map, ALL steps of a chunk are drawn in one
+ * pass (a citizen's exposure step is the earliest step at which any of its draws succeeds -- one atomicMin on
+ * the citizen word per successful draw).  esim_chunk_timing: device time (ms), steps and number of such chunks
+ * since the last call (measured while kernel timing is enabled). */
 int  esim_future_infected(esim_ctx *ctx);
 int  esim_run_free(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_done);
-int  esim_set_pipeline(esim_ctx *ctx, int enable);
+int  esim_set_pipeline(esim_ctx *ctx, int level);
+int  esim_chunk_timing(esim_ctx *ctx, double *total_ms, uint64_t *steps, uint64_t *chunks);
 /* Record log read-back for split-phase runs (records first..first+n-1, 1-based time steps). */
 int  esim_read_records(esim_ctx *ctx, uint32_t first_step, uint32_t n, esim_step_result *out);
 /* The HIP stream all work of this context is enqueued on (hipStream_t as void*).  esim_set_stream

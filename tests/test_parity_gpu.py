@@ -27,10 +27,10 @@ def assert_same_state(sim, orc):
         assert (g[k] == o[k]).all(), k
 
 
-# every scenario runs four ways: pipelined chunks (default: one kernel per step until a vaccination programme
-# starts, then sequential steps), and sequential steps only with the default hand-over between the persistent
+# every scenario runs five ways: time-parallel chunks (default: all steps of a chunk drawn in one pass until a
+# vaccination programme starts, then sequential steps), chunks as one kernel per step, and sequential steps only with the default hand-over between the persistent
 # single-workgroup kernel and the multi-workgroup kernels, multi-workgroup kernels only, persistent kernel only
-SMALL_LIMITS = ("pipe", None, 0, 1 << 30)
+SMALL_LIMITS = ("tp", "pipe", None, 0, 1 << 30)
 
 
 def run_both(pop, steps, check_state_every=None, small_limits=SMALL_LIMITS, **params):
@@ -41,8 +41,12 @@ def run_both(pop, steps, check_state_every=None, small_limits=SMALL_LIMITS, **pa
 def _run_both(pop, steps, check_state_every, small_limit, **params):
     ep = _lib.default_params(**params)
     sim = Simulator(pop, ep)
-    if small_limit != "pipe":
-        sim.set_pipeline(False)
+    if small_limit == "tp":
+        sim.set_pipeline(2)                       # time-parallel chunks (default)
+    elif small_limit == "pipe":
+        sim.set_pipeline(1)                       # one kernel per step
+    else:
+        sim.set_pipeline(0)                       # sequential steps
         if small_limit is not None:
             sim.set_small_step_limit(small_limit)
     orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
@@ -97,18 +101,18 @@ def test_step_by_step_equals_run():
 
 
 def test_york_default_params_1000_steps():
-    run_both(Population.synthetic("york"), 1000, small_limits=("pipe", 0))
+    run_both(Population.synthetic("york"), 1000, small_limits=("tp", "pipe", 0))
 
 
 def test_york_full_5000_steps_vaccination_85():
     # BASELINE.json configs[1]: York, 5000 steps, fixed Philox seed vs CPU counts; v1.7.1's rate 85/step
-    run_both(Population.synthetic("york"), 5000, small_limits=("pipe", None), vaccination_rate=85, vaccination_threshold=0.003)
+    run_both(Population.synthetic("york"), 5000, small_limits=("tp", "pipe", None), vaccination_rate=85, vaccination_threshold=0.003)
 
 
 def test_yh_census_config_1500_steps():
     # BASELINE.json configs[2]: Yorkshire & Humber (5 249 772 citizens, 17 246 Output Areas) on one GPU;
     # 1500 of the 5000 steps keeps the oracle within ~20 s
-    run_both(Population.synthetic("yh_census"), 1500, small_limits=("pipe",))
+    run_both(Population.synthetic("yh_census"), 1500, small_limits=("tp", "pipe"))
 
 
 def test_big_routes_and_u8_truncation():
