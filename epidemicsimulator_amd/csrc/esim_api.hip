@@ -318,16 +318,22 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     // hash map of the time-parallel chunks: room for ~2 marks per (Infected, step) pair at < 1/2 load
     {
         uint32_t cap = 1u << 20;
-        while (cap < (1u << 26) && cap < N / 4u) cap <<= 1;
+        while (cap < (1u << 24) && cap < N / 16u) cap <<= 1;
         if (const char *e = std::getenv("ESIM_HASH_LOG2")) cap = 1u << std::min(28, std::max(4, std::atoi(e)));
         d.hcap = cap;
+        d.items_cap = cap / 4u;                     // load factor <= 1/4; one count vector of FREE_MAX steps per item
         if ((rc = dev_alloc(c, &d.hkey, cap))) return rc;
-        if ((rc = dev_alloc(c, &d.hcnt, cap))) return rc;
-        if ((rc = dev_alloc(c, &d.hitems, cap))) return rc;
+        if ((rc = dev_alloc(c, &d.hval, cap))) return rc;
+        if ((rc = dev_alloc(c, &d.hitems, d.items_cap))) return rc;
+        if ((rc = dev_alloc(c, &d.vec, (size_t)d.items_cap * FREE_MAX))) return rc;
+        d.units_cap = (uint32_t)std::min<size_t>((size_t)N / 8u + 1024u, 1u << 26);
+        if ((rc = dev_alloc(c, &d.unit_item, d.units_cap))) return rc;
+        if ((rc = dev_alloc(c, &d.unit_lo, d.units_cap))) return rc;
+        HIP_TRY(c, hipMemset(d.hval, 0xFF, sizeof(uint32_t) * cap));
         if ((rc = dev_alloc(c, &d.newexp, (size_t)N + 1))) return rc;
         if ((rc = dev_alloc(c, &d.cursor, FREE_MAX))) return rc;
         HIP_TRY(c, hipMemset(d.hkey, 0xFF, sizeof(unsigned long long) * cap));
-        HIP_TRY(c, hipMemset(d.hcnt, 0, sizeof(uint32_t) * cap));
+        HIP_TRY(c, hipMemset(d.vec, 0, sizeof(uint32_t) * (size_t)d.items_cap * FREE_MAX));
         HIP_TRY(c, hipMemset(d.cursor, 0, sizeof(uint32_t) * FREE_MAX));
     }
     for (int p = 0; p < (int)MARK_SLOTS; ++p) {
@@ -573,7 +579,7 @@ int run_sequential(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, ui
 int run_chunk(esim_ctx_impl *c, uint32_t n_ahead, uint32_t *executed, Ctrl *state_before)
 {
     Dev &d = c->d;
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(128), 0, c->stream, d, n_ahead, c->time_parallel ? 1 : 0);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, n_ahead, c->time_parallel ? 1 : 0);
     Ctrl h;
     HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -586,8 +592,9 @@ int run_chunk(esim_ctx_impl *c, uint32_t n_ahead, uint32_t *executed, Ctrl *stat
         // every step of the chunk in one pass: marks of all steps, draws of all (item, step) pairs, then the books
         const bool tk = c->kernel_timing;
         if (tk) { if (!c->cev[0]) { (void)hipEventCreate(&c->cev[0]); (void)hipEventCreate(&c->cev[1]); } HIP_TRY(c, hipEventRecord(c->cev[0], c->stream)); }
-        hipLaunchKernelGGL(k_chunk_mark, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d, t0, n);
+        hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d, t0, n);
         hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d, t0, n);
+        hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d, t0, n);
         hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);
         hipLaunchKernelGGL(k_batch_finish, dim3(1), dim3(FIN_TPB), 0, c->stream, d, t0, n);
         hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d, t0);

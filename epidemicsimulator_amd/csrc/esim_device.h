@@ -66,10 +66,10 @@ struct Ctrl {
     uint32_t small_done;        // steps executed by the last k_small launch
     uint32_t chunk_ok;          // steps of the current chunk that may run pipelined (k_decide)
     uint32_t chunk_parallel;    // 1: the chunk's marks fit the hash map, all its steps can be drawn in one pass
-    uint32_t chunk_pairs;       // (Infected citizen, step) pairs of the chunk on this shard (k_future)
+    uint32_t chunk_pairs;       // log entries that are Infected in some step of the chunk, this shard (k_future)
     uint32_t n_items;           // marked (building | room | route, step) entries of the chunk
     uint32_t n_newexp;          // citizens exposed in the chunk
-    uint32_t pad[2];
+    uint32_t n_units, unit_next; // deferred units of long member lists (k_chunk_units)
 };
 
 // What is in force during one step of a pipelined chunk (k_decide fills dec[0..chunk_ok]).
@@ -101,10 +101,14 @@ struct Dev {
     uint32_t *exp_step;         // [2 * (max_steps + 2)] successful exposures per step: [2t] buildings, [2t+1] buses
     struct Decision *dec;       // [FREE_MAX + 1]
     // time-parallel chunks: infected per (building | room | route, step of the chunk) in an open-addressing hash map
-    unsigned long long *hkey;   // [hcap] (slot id << 8 | step offset), HKEY_EMPTY when free
-    uint32_t *hcnt;             // [hcap]
+    unsigned long long *hkey;   // [hcap] slot id (building | n_bld + room | n_bld + n_room + route), HKEY_EMPTY when free
+    uint32_t *hval;             // [hcap] item index of the key
     uint32_t hcap;              // power of two
-    uint32_t *hitems;           // [hcap / 2] occupied entries of the chunk
+    uint32_t *hitems;           // [items_cap] hash slot of each item of the chunk
+    uint32_t *vec;              // [items_cap][FREE_MAX] infected standing in the item in each step of the chunk
+    uint32_t items_cap;
+    uint32_t *unit_item, *unit_lo;  // [units_cap] item | kind << 30, first member of the unit
+    uint32_t units_cap;
     uint32_t *newexp;           // [n] citizens exposed in the chunk
     uint32_t *cursor;           // [FREE_MAX] per-step write cursors into the log
     uint32_t max_route;         // riders of the largest route

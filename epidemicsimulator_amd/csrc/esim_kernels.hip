@@ -489,66 +489,82 @@ __global__ __launch_bounds__(FIN_TPB) void k_future(Dev d, uint32_t n_ahead)
     { const int k = base_idx + (int)tid; win[tid] = (k >= 0 && k < (int)TE_SLOTS) ? d.hist[k] : 0u; }
     __syncthreads();
     block_scan_1024(win, wtmp);                                            // win[i] = sum of hist[base_idx .. base_idx + i]
-    __shared__ uint32_t pairs;
-    if (tid == 0) pairs = 0u;
-    __syncthreads();
     if (tid < n_ahead) {
         // Infected window of step t0 + tid: entries [tid, tid + it] of the loaded range
         const uint32_t hi = win[tid + (uint32_t)it], lo = tid ? win[tid - 1u] : 0u;
         d.xf[tid] = hi - lo;
-        atomicAdd(&pairs, hi - lo);
     }
-    __syncthreads();
-    if (tid == 0) { ctrl->free_base = t0; ctrl->chunk_pairs = pairs; }
+    if (tid == 0) {
+        ctrl->free_base = t0;
+        // citizens Infected in at least one step of the chunk: exposure steps [first window's low end, last window's top]
+        ctrl->chunk_pairs = n_ahead ? win[n_ahead - 1u + (uint32_t)it] : 0u;
+    }
 }
 
-__global__ __launch_bounds__(128) void k_decide(Dev d, uint32_t n_ahead, int allow_parallel)
+__global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t n_ahead, int allow_parallel)
 {
-    __shared__ double xs[FREE_MAX];
-    __shared__ Decision ds[FREE_MAX + 1];
+    // one wavefront: lane l evaluates the threshold tests of steps l and 64 + l (interventions.rs:116-170, all
+    // strict), __ballot packs them into wave-uniform bit masks, and the state machine then walks the steps with
+    // scalar bit tests only; every lane keeps the decisions of its own two steps
     Ctrl *ctrl = d.ctrl;
-    if (threadIdx.x < FREE_MAX) xs[threadIdx.x] = threadIdx.x < n_ahead ? (double)d.xf[threadIdx.x] / (double)d.n_global : 0.0;
-    __syncthreads();
-    __shared__ uint32_t n_ok_s;
-    if (threadIdx.x == 0) {
-        const uint32_t t0 = ctrl->t;
-        uint32_t lockdown = ctrl->lockdown, mask = ctrl->mask, at_work = ctrl->at_work, bus_dir = ctrl->bus_dir;
-        uint32_t n_ok = 0;
-        if (!ctrl->have_elig && !ctrl->vacc_active && !ctrl->finished && !ctrl->error && ctrl->free_base == t0) {
-            for (uint32_t j = 0; j < n_ahead && j < FREE_MAX && t0 + j <= d.max_steps; ++j) {
-                const double x = xs[j];                                       // infected_percentage, statistics.rs:252
-                if (d.thr_vacc < x) break;                                    // this step starts the programme: not pipelined
-                if (!lockdown) {                                              // citizen.rs:176-206
-                    const uint32_t h = (t0 + j) % 24u;
-                    if (h == d.start_hour - 1u) bus_dir = 1u;
-                    else if (h == d.start_hour) { at_work = 1u; bus_dir = 0u; }
-                    else if (h == d.end_hour - 1u) bus_dir = 2u;
-                    else if (h == d.end_hour) { at_work = 0u; bus_dir = 0u; }
-                    else bus_dir = 0u;
-                }
-                Decision q; q.lockdown = lockdown; q.mask = mask; q.at_work = at_work; q.bus_dir = bus_dir;
-                ds[j] = q;
-                lockdown = d.thr_lockdown < x ? 1u : 0u;                      // interventions.rs:116-128
-                if (mask == ESIM_MASK_NONE) { if (d.thr_mask_pt < x) mask = ESIM_MASK_PUBLIC_TRANSPORT; }   // :142-180
-                else if (mask == ESIM_MASK_PUBLIC_TRANSPORT) {
-                    if (x < d.thr_mask_pt) mask = ESIM_MASK_NONE;
-                    else if (d.thr_mask_all < x) mask = ESIM_MASK_EVERYWHERE;
-                } else if (x < d.thr_mask_all) mask = ESIM_MASK_PUBLIC_TRANSPORT;
-                n_ok = j + 1u;
-            }
-        }
-        Decision q; q.lockdown = lockdown; q.mask = mask; q.at_work = at_work; q.bus_dir = bus_dir;
-        ds[n_ok] = q;                                                         // what is in force after the chunk
-        n_ok_s = n_ok;
-        ctrl->chunk_ok = n_ok;
-        // every (Infected, step) pair marks at most a building and a room: keep the map under half full
-        ctrl->chunk_parallel = (allow_parallel && d.hcap && d.max_route <= CHUNK_ROUTE_MAX &&
-                                (unsigned long long)ctrl->chunk_pairs * 4ull <= (unsigned long long)d.hcap) ? 1u : 0u;
-        ctrl->n_items = 0u; ctrl->n_newexp = 0u;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t lim_in = n_ahead < FREE_MAX ? n_ahead : FREE_MAX;
+    unsigned long long m_vacc[2], m_lock[2], m_pt_up[2], m_pt_dn[2], m_all_up[2], m_all_dn[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t j = 64u * r + lane;
+        const bool in = j < lim_in;
+        const double x = in ? (double)d.xf[j] / (double)d.n_global : 0.0;   // infected_percentage, statistics.rs:252
+        m_vacc[r] = __ballot(in && d.thr_vacc < x);
+        m_lock[r] = __ballot(in && d.thr_lockdown < x);
+        m_pt_up[r] = __ballot(in && d.thr_mask_pt < x);
+        m_pt_dn[r] = __ballot(in && x < d.thr_mask_pt);
+        m_all_up[r] = __ballot(in && d.thr_mask_all < x);
+        m_all_dn[r] = __ballot(in && x < d.thr_mask_all);
     }
-    if (threadIdx.x < FREE_MAX) d.cursor[threadIdx.x] = 0u;
-    __syncthreads();
-    if (threadIdx.x <= n_ok_s) d.dec[threadIdx.x] = ds[threadIdx.x];
+    const uint32_t t0 = ctrl->t;
+    uint32_t lockdown = ctrl->lockdown, mask = ctrl->mask, at_work = ctrl->at_work, bus_dir = ctrl->bus_dir;
+    const bool ok = !ctrl->have_elig && !ctrl->vacc_active && !ctrl->finished && !ctrl->error && ctrl->free_base == t0;
+    Decision mine0 = { 0u, 0u, 0u, 0u }, mine1 = { 0u, 0u, 0u, 0u };
+    uint32_t n_ok = 0;
+    uint32_t h = t0 % 24u;
+    const uint32_t lim = ok ? lim_in : 0u;
+    for (uint32_t j = 0; j < lim && t0 + j <= d.max_steps; ++j) {
+        const uint32_t r = j >> 6;
+        const unsigned long long bit = 1ull << (j & 63u);
+        if (m_vacc[r] & bit) break;                                       // this step starts the programme: not part of the chunk
+        if (!lockdown) {                                                  // citizen.rs:176-206
+            if (h == d.start_hour - 1u) bus_dir = 1u;
+            else if (h == d.start_hour) { at_work = 1u; bus_dir = 0u; }
+            else if (h == d.end_hour - 1u) bus_dir = 2u;
+            else if (h == d.end_hour) { at_work = 0u; bus_dir = 0u; }
+            else bus_dir = 0u;
+        }
+        h = h == 23u ? 0u : h + 1u;
+        const Decision q = { lockdown, mask, at_work, bus_dir };
+        if (j == lane) mine0 = q;
+        if (j == 64u + lane) mine1 = q;
+        lockdown = (m_lock[r] & bit) ? 1u : 0u;                           // interventions.rs:116-128
+        if (mask == ESIM_MASK_NONE) { if (m_pt_up[r] & bit) mask = ESIM_MASK_PUBLIC_TRANSPORT; }     // :142-180
+        else if (mask == ESIM_MASK_PUBLIC_TRANSPORT) {
+            if (m_pt_dn[r] & bit) mask = ESIM_MASK_NONE;
+            else if (m_all_up[r] & bit) mask = ESIM_MASK_EVERYWHERE;
+        } else if (m_all_dn[r] & bit) mask = ESIM_MASK_PUBLIC_TRANSPORT;
+        n_ok = j + 1u;
+    }
+    const Decision after = { lockdown, mask, at_work, bus_dir };          // what is in force after the chunk
+    if (lane < n_ok) d.dec[lane] = mine0;
+    if (64u + lane < n_ok) d.dec[64u + lane] = mine1;
+    if (lane == (n_ok & 63u)) d.dec[n_ok] = after;
+    if (lane == 0) {
+        ctrl->chunk_ok = n_ok;
+        // a citizen marks at most its home, its work building, its room and its route
+        ctrl->chunk_parallel = (allow_parallel && d.items_cap && d.max_route <= CHUNK_ROUTE_MAX &&
+                                (unsigned long long)ctrl->chunk_pairs * 4ull <= (unsigned long long)d.items_cap) ? 1u : 0u;
+        ctrl->n_items = 0u; ctrl->n_newexp = 0u; ctrl->n_units = 0u; ctrl->unit_next = 0u;
+    }
+    d.cursor[lane] = 0u;
+    if (lane < FREE_MAX - 64u) d.cursor[64u + lane] = 0u;
 }
 
 // Marks of the first step of a chunk (the later ones are made by the k_pipe of the step before).
@@ -589,32 +605,69 @@ __device__ __forceinline__ uint32_t hash64(unsigned long long k)
     return (uint32_t)k;
 }
 
-__device__ __forceinline__ void mark_add(const Dev &d, Ctrl *ctrl, unsigned long long key)
+// Item of `key` (a building, a room or a route that somebody Infected stands in during the chunk), claimed if the
+// key is new.  Two phases, so that a wavefront has published ALL its own claims before any of its lanes waits:
+// item_claim probes without ever waiting -- the claimer allocates the index and publishes it; item_wait is called
+// after the lanes have reconverged by those that found the key already there, and waits (bounded) for the index.
+// The claimer it waits for sits in a wavefront that is past its own item_claim or inside it, never in item_wait.
+#define HVAL_PENDING 0xFFFFFFFFu
+__device__ __forceinline__ uint32_t item_claim(const Dev &d, Ctrl *ctrl, unsigned long long key, uint32_t &slot, bool &pending)
 {
     uint32_t h = hash64(key) & (d.hcap - 1u);
+    pending = false;
     for (uint32_t probe = 0; probe < d.hcap; ++probe) {
         const unsigned long long old = atomicCAS(&d.hkey[h], HKEY_EMPTY, key);
-        if (old == HKEY_EMPTY) { atomicAdd(&d.hcnt[h], 1u); append(d.hitems, &ctrl->n_items, h); return; }
-        if (old == key) { atomicAdd(&d.hcnt[h], 1u); return; }
+        if (old == HKEY_EMPTY) {
+            uint32_t v = atomicAdd(&ctrl->n_items, 1u);
+            if (v >= d.items_cap) { ctrl->error = (uint32_t)(-ESIM_ERANGE); v = 0u; } else d.hitems[v] = h;
+            __hip_atomic_store(&d.hval[h], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            slot = h;
+            return v;
+        }
+        if (old == key) { slot = h; pending = true; return 0u; }
         h = (h + 1u) & (d.hcap - 1u);
     }
     ctrl->error = (uint32_t)(-ESIM_ERANGE);
+    slot = 0u;
+    return 0u;
 }
 
-__device__ __forceinline__ uint32_t mark_get(const Dev &d, unsigned long long key)
+__device__ __forceinline__ uint32_t item_wait(const Dev &d, Ctrl *ctrl, uint32_t slot)
+{
+    for (uint32_t spin = 0; spin < (1u << 20); ++spin) {
+        const uint32_t v = __hip_atomic_load(&d.hval[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != HVAL_PENDING) return v;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    ctrl->error = (uint32_t)(-ESIM_ERANGE);
+    return 0u;
+}
+
+// Item index of `key` once every claim of the chunk is done, 0xFFFFFFFF when it has no item.
+__device__ __forceinline__ uint32_t item_find(const Dev &d, unsigned long long key)
 {
     uint32_t h = hash64(key) & (d.hcap - 1u);
     for (uint32_t probe = 0; probe < d.hcap; ++probe) {
         const unsigned long long k = d.hkey[h];
-        if (k == key) return d.hcnt[h];
-        if (k == HKEY_EMPTY) return 0u;
+        if (k == key) return d.hval[h];
+        if (k == HKEY_EMPTY) return 0xFFFFFFFFu;
         h = (h + 1u) & (d.hcap - 1u);
     }
-    return 0u;
+    return 0xFFFFFFFFu;
 }
 
-// generate_exposures (simulator.rs:181-198) for every step of the chunk: one thread per (log entry, step).
-__global__ __launch_bounds__(TPB) void k_chunk_mark(Dev d, uint32_t t0, uint32_t n)
+// Where an Infected citizen stands in step t0 + j of the chunk (simulator.rs:181-198): bit 0 in the home
+// building, bit 1 in the work building, bit 2 on the bus.  0 when not Infected in that step.
+__device__ __forceinline__ uint32_t where_in_step(const Dev &d, uint32_t w, uint32_t s, const Decision &q)
+{
+    if (status_of(CW_TE(w), s, d.exposed_time, d.infected_time) != ESIM_INFECTED) return 0u;
+    if (q.bus_dir && (w & FL_USES_PT)) return 4u;
+    return (q.at_work && (w & FL_HAS_WORK)) ? 2u : 1u;
+}
+
+// generate_exposures (simulator.rs:181-198) for every step of the chunk: one wavefront per citizen
+// that is Infected somewhere in the chunk; lanes are the steps.
+__global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d, uint32_t t0, uint32_t n)
 {
     Ctrl *ctrl = d.ctrl;
     {
@@ -632,130 +685,225 @@ __global__ __launch_bounds__(TPB) void k_chunk_mark(Dev d, uint32_t t0, uint32_t
     const int hi_te = (int)(t0 + n - 1u + TE_BIAS) - (int)d.exposed_time - 1;                    // Infected in step t0 + n - 1
     if (hi_te < 0) return;
     const uint32_t i0 = d.log_off[lo_te < 0 ? 0 : lo_te], i1 = d.log_off[hi_te + 1];
-    const unsigned long long total = (unsigned long long)(i1 - i0) * n;
-    for (unsigned long long p = (unsigned long long)blockIdx.x * TPB + threadIdx.x; p < total; p += (unsigned long long)gridDim.x * TPB) {
-        const uint32_t e = i0 + (uint32_t)(p / n), j = (uint32_t)(p % n), s = t0 + j;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    const Decision q0 = lane < n ? d.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
+    const Decision q1 = 64u + lane < n ? d.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
+    for (uint32_t e = i0 + wave; e < i1; e += n_waves) {
         const uint32_t c = d.log[e];
         const uint32_t w = d.cit[c];
-        if (status_of(CW_TE(w), s, d.exposed_time, d.infected_time) != ESIM_INFECTED) continue;
-        const Decision q = d.dec[j];
-        if (q.bus_dir && (w & FL_USES_PT)) {                                  // simulator.rs:181-186
-            mark_add(d, ctrl, ((unsigned long long)(d.n_bld + d.n_room + d.route_of[c]) << 8) | j);
-        } else {                                                              // :187-198
-            const bool atw = q.at_work && (w & FL_HAS_WORK);
-            mark_add(d, ctrl, ((unsigned long long)(atw ? d.work[c] : d.home[c]) << 8) | j);
-            if (atw && (w & FL_WORK_SCHOOL)) mark_add(d, ctrl, ((unsigned long long)(d.n_bld + d.room[c]) << 8) | j);
-        }
+        const uint32_t p0 = lane < n ? where_in_step(d, w, t0 + lane, q0) : 0u;
+        const uint32_t p1 = 64u + lane < n ? where_in_step(d, w, t0 + 64u + lane, q1) : 0u;
+        const bool any_home = __any((p0 | p1) & 1u), any_work = __any((p0 | p1) & 2u), any_bus = __any((p0 | p1) & 4u);
+        const bool school = w & FL_WORK_SCHOOL;
+        if (!any_home && !any_work && !any_bus) continue;
+        // lanes 0..3 own one key each: home building, work building, room, route
+        unsigned long long key = HKEY_EMPTY;
+        if (lane == 0 && any_home) key = d.home[c];
+        if (lane == 1 && any_work) key = d.work[c];
+        if (lane == 2 && any_work && school) key = (unsigned long long)d.n_bld + d.room[c];
+        if (lane == 3 && any_bus) key = (unsigned long long)d.n_bld + d.n_room + d.route_of[c];
+        uint32_t v = 0xFFFFFFFFu, slot = 0u;
+        bool pending = false;
+        if (key != HKEY_EMPTY) v = item_claim(d, ctrl, key, slot, pending);   // every claim of this wavefront is published here ...
+        __builtin_amdgcn_wave_barrier();
+        if (pending) v = item_wait(d, ctrl, slot);                            // ... before any lane waits for somebody else's
+        const uint32_t v_home = __shfl(v, 0, 64), v_work = __shfl(v, 1, 64), v_room = __shfl(v, 2, 64), v_bus = __shfl(v, 3, 64);
+        if (p0 & 1u) atomicAdd(&d.vec[(size_t)v_home * FREE_MAX + lane], 1u);
+        if (p1 & 1u) atomicAdd(&d.vec[(size_t)v_home * FREE_MAX + 64u + lane], 1u);
+        if (p0 & 2u) { atomicAdd(&d.vec[(size_t)v_work * FREE_MAX + lane], 1u); if (school) atomicAdd(&d.vec[(size_t)v_room * FREE_MAX + lane], 1u); }
+        if (p1 & 2u) { atomicAdd(&d.vec[(size_t)v_work * FREE_MAX + 64u + lane], 1u); if (school) atomicAdd(&d.vec[(size_t)v_room * FREE_MAX + 64u + lane], 1u); }
+        if (p0 & 4u) atomicAdd(&d.vec[(size_t)v_bus * FREE_MAX + lane], 1u);
+        if (p1 & 4u) atomicAdd(&d.vec[(size_t)v_bus * FREE_MAX + 64u + lane], 1u);
     }
 }
 
-// A successful draw of citizen m in step s (bus: on public transport).
-__device__ __forceinline__ void expose_min(const Dev &d, Ctrl *ctrl, uint32_t m, uint32_t w, uint32_t s, uint32_t bus)
+// A successful draw of citizen m in step s (bus: on public transport).  Returns the word the citizen has now.
+__device__ __forceinline__ uint32_t expose_min(const Dev &d, Ctrl *ctrl, uint32_t m, uint32_t w, uint32_t s, uint32_t bus)
 {
     const uint32_t cand = CW_MAKE(s + TE_BIAS, bus | (w & CW_FLAGS));
     const uint32_t prev = atomicMin(&d.cit[m], cand);
     if (cand < prev && CW_TE(prev) == TE_SUSCEPTIBLE) append(d.newexp, &ctrl->n_newexp, m);   // first exposure in this chunk
+    return cand < prev ? cand : prev;
 }
 
-__device__ __forceinline__ void member_list_chunk(const Dev &d, Ctrl *ctrl, const uint32_t *idx, uint32_t lo, uint32_t hi, uint32_t gl,
-                                                  uint32_t kind, uint32_t n, uint32_t k, uint32_t s, uint32_t mask, uint32_t at_work)
+struct ChunkShared {
+    Decision dec[FREE_MAX];
+    uint64_t thr[512];
+    uint32_t s_key[CHUNK_ROUTE_MAX];
+    uint16_t s_bus[CHUNK_ROUTE_MAX];
+    uint8_t s_inf[CHUNK_ROUTE_MAX];
+    uint32_t s_cnt[CHUNK_ROUTE_MAX + 1];
+};
+
+// One member list of one item, all steps of the chunk, by one wavefront: lane = member slot u (0..7) + 8 * step
+// residue g (0..7); a lane draws for its member in the steps g, g + 8, ..., g + 88 in which somebody Infected stands
+// in the item (cnt12 / sch12: the item's and the school's counts of those twelve steps).  No ordering is needed
+// between steps or lists: every successful draw is one atomicMin.  kind 0 residents, 1 workers, 2 room participants.
+__device__ __forceinline__ void member_list_wave(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, const uint32_t *idx,
+                                                 uint32_t lo, uint32_t hi, uint32_t u, uint32_t g, uint32_t kind,
+                                                 const uint32_t (&cnt12)[12], const uint32_t (&sch12)[12], uint32_t t0, uint32_t n)
 {
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
-    for (uint32_t base = lo + gl; base < hi; base += 32u) {
-        uint32_t m[4], w[4];
-        bool ok[4];
+    for (uint32_t q = lo + u; q < hi; q += 8u) {
+        const uint32_t m = idx ? idx[q] : q;
+        uint32_t w = d.cit[m];
+        const uint32_t te0 = CW_TE(w);
+        if (te0 >= TE_RECOVERED && te0 != TE_SUSCEPTIBLE) continue;
+        const uint32_t gid = d.id_base + m;
+        const bool same = w & FL_SAME_AREA;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const uint32_t q = base + 8u * u; ok[u] = q < hi; m[u] = ok[u] ? (idx ? idx[q] : q) : 0u; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = ok[u] ? d.cit[m[u]] : 0u;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (!ok[u]) continue;
-            const uint32_t te = CW_TE(w[u]), fl = w[u];
-            // Susceptible when this list is walked in step s: never exposed, or so far only exposed by something
-            // that comes later (a later step, or a bus of this step) -- that exposure may be undercut
-            if (w[u] <= CW_MAKE(s + TE_BIAS, fl & CW_FLAGS) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE)) continue;
-            const bool same = fl & FL_SAME_AREA;
-            if (kind == 0u) { if (at_work && (fl & FL_HAS_WORK) && !same) continue; }        // simulator.rs:324
+        for (int i = 0; i < 12; ++i) {
+            const uint32_t j = g + 8u * i;
+            const uint32_t cnt = cnt12[i];
+            if (j >= n || !cnt) continue;
+            const uint32_t s = t0 + j;
+            // Susceptible when this list is walked in step s: never exposed, or so far only exposed by something that
+            // comes later (a later step, or a bus of this step) -- that exposure may be undercut
+            if (w <= CW_MAKE(s + TE_BIAS, w & CW_FLAGS)) continue;
+            const uint32_t at_work = sm.dec[j].at_work, mask = sm.dec[j].mask;
+            if (kind == 0u) { if (at_work && (w & FL_HAS_WORK) && !same) continue; }       // simulator.rs:324
             else if (!at_work && !same) continue;
-            const uint64_t thr = threshold(d, fl, mask, n);
-            const uint32_t g = d.id_base + m[u];
+            const uint32_t nn = kind == 2u ? sch12[i] : cnt;                                // exposure_count: infected in the building
+            const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
+            const uint64_t thr = sm.thr[row * 256u + (nn & 255u)];
             bool hit = false;
-            if (kind == 2u) { for (uint32_t j = 0; j < k && !hit; ++j) hit = esim_u53(seed, g, s, ESIM_SLOT_ROOM0 + j) < thr; }
-            else hit = esim_u53(seed, g, s, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK) < thr;
-            if (hit) expose_min(d, ctrl, m[u], w[u], s, 0u);
+            if (kind == 2u) { for (uint32_t k = 0; k < cnt && !hit; ++k) hit = esim_u53(seed, gid, s, ESIM_SLOT_ROOM0 + k) < thr; }
+            else hit = esim_u53(seed, gid, s, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK) < thr;
+            if (hit) w = expose_min(d, ctrl, m, w, s, 0u);
         }
     }
 }
 
-// apply_exposures (simulator.rs:262-405) for every marked (item, step) of the chunk.
+// Long member lists are cut into units of UNIT_MEMBERS members that any wavefront can take (k_chunk_units), so that
+// one 200-member workplace does not keep a single wavefront busy while the chip idles.
+#define UNIT_MEMBERS 16u
+__device__ __forceinline__ void defer_units(const Dev &d, Ctrl *ctrl, uint32_t v, uint32_t kind, uint32_t lo, uint32_t hi, uint32_t lane)
+{
+    const uint32_t n_units = (hi - lo + UNIT_MEMBERS - 1u) / UNIT_MEMBERS;
+    uint32_t start = 0;
+    if (lane == 0) start = atomicAdd(&ctrl->n_units, n_units);
+    start = __shfl(start, 0, 64);
+    for (uint32_t i = lane; i < n_units; i += 64u) {
+        if (start + i >= d.units_cap) { ctrl->error = (uint32_t)(-ESIM_ERANGE); break; }
+        d.unit_item[start + i] = v | (kind << 30);
+        d.unit_lo[start + i] = lo + i * UNIT_MEMBERS;
+    }
+}
+
+// apply_exposures (simulator.rs:262-405) for every item and every step of the chunk.
 __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t t0, uint32_t n)
 {
-    __shared__ uint32_t s_key[CHUNK_ROUTE_MAX];
-    __shared__ uint16_t s_bus[CHUNK_ROUTE_MAX];
-    __shared__ uint8_t s_inf[CHUNK_ROUTE_MAX];
-    __shared__ uint32_t s_cnt[CHUNK_ROUTE_MAX + 1];
+    __shared__ ChunkShared sm;
     Ctrl *ctrl = d.ctrl;
+    for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
+    for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
+    __syncthreads();
     const uint32_t n_items = ld(&ctrl->n_items);
-    const uint32_t lane = threadIdx.x & 63u, grp = lane >> 3, gl = lane & 7u;
+    const uint32_t lane = threadIdx.x & 63u, u = lane & 7u, g = lane >> 3;
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
     const uint32_t route_base = d.n_bld + d.n_room;
-    // (1) buildings and school rooms: groups of 8 lanes
-    for (uint32_t base = wave * 8u; base < n_items; base += n_waves * 8u) {
-        const uint32_t it = base + grp;
-        if (it >= n_items) continue;
-        const uint32_t h = d.hitems[it];
-        const unsigned long long key = d.hkey[h];
-        const uint32_t id = (uint32_t)(key >> 8), j = (uint32_t)(key & 0xFFu), s = t0 + j;
-        if (id >= route_base || j >= n) continue;
-        const Decision q = d.dec[j];
-        const uint32_t cnt = d.hcnt[h];
+    // (1) buildings and school rooms: one wavefront per item
+    for (uint32_t v = wave; v < n_items; v += n_waves) {
+        const uint32_t id = (uint32_t)d.hkey[d.hitems[v]];
+        if (id >= route_base) continue;
+        uint32_t cnt12[12], sch12[12];
         if (id < d.n_bld) {
-            if (d.bld_type[id] == ESIM_SCHOOL) continue;                       // School::find_exposures works per room
-            member_list_chunk(d, ctrl, d.res_idx, d.res_off[id], d.res_off[id + 1], gl, 0u, cnt, 0u, s, q.mask, q.at_work);
-            member_list_chunk(d, ctrl, d.wrk_idx, d.wrk_off[id], d.wrk_off[id + 1], gl, 1u, cnt, 0u, s, q.mask, q.at_work);
+            if (d.bld_type[id] == ESIM_SCHOOL) continue;                      // School::find_exposures works per room
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { cnt12[i] = d.vec[(size_t)v * FREE_MAX + g + 8u * i]; sch12[i] = 0u; }
+            // Household / Workplace::find_exposures: every registered occupant (building.rs:202-204,278-280)
+            const uint32_t r0 = d.res_off[id], r1 = d.res_off[id + 1], w0 = d.wrk_off[id], w1 = d.wrk_off[id + 1];
+            if (r1 - r0 <= UNIT_MEMBERS) member_list_wave(d, ctrl, sm, d.res_idx, r0, r1, u, g, 0u, cnt12, sch12, t0, n);
+            else defer_units(d, ctrl, v, 0u, r0, r1, lane);
+            if (w1 - w0 <= UNIT_MEMBERS) member_list_wave(d, ctrl, sm, d.wrk_idx, w0, w1, u, g, 1u, cnt12, sch12, t0, n);
+            else defer_units(d, ctrl, v, 1u, w0, w1, lane);
         } else {
             const uint32_t r = id - d.n_bld;
-            const uint32_t nsch = mark_get(d, ((unsigned long long)d.room_bld[r] << 8) | j);   // infected in the whole school
-            member_list_chunk(d, ctrl, d.room_idx, d.room_off[r], d.room_off[r + 1], gl, 2u, nsch, cnt, s, q.mask, q.at_work);
+            const uint32_t v_sch = item_find(d, d.room_bld[r]);               // infected in the whole school, per step
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                cnt12[i] = d.vec[(size_t)v * FREE_MAX + g + 8u * i];
+                sch12[i] = v_sch != 0xFFFFFFFFu ? d.vec[(size_t)v_sch * FREE_MAX + g + 8u * i] : 0u;
+            }
+            // School::find_exposures: the room once per infected in it (building.rs:494-522)
+            const uint32_t m0 = d.room_off[r], m1 = d.room_off[r + 1];
+            if (m1 - m0 <= UNIT_MEMBERS) member_list_wave(d, ctrl, sm, d.room_idx, m0, m1, u, g, 2u, cnt12, sch12, t0, n);
+            else defer_units(d, ctrl, v, 2u, m0, m1, lane);
         }
     }
-    // (2) routes: one workgroup per (route, step); rank by (Philox key, id) through LDS, buses are runs of
-    // bus_capacity ranks (simulator.rs:362-388)
+    // (2) routes: one workgroup per route, its bus steps one after the other; rank by (Philox key, id) through LDS,
+    // buses are runs of bus_capacity ranks (simulator.rs:362-388)
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
-    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const uint32_t h = d.hitems[it];
-        const unsigned long long key = d.hkey[h];
-        const uint32_t id = (uint32_t)(key >> 8), j = (uint32_t)(key & 0xFFu), s = t0 + j;
-        if (id < route_base || j >= n) continue;                              // block-uniform
+    for (uint32_t v = blockIdx.x; v < n_items; v += gridDim.x) {
+        const uint32_t id = (uint32_t)d.hkey[d.hitems[v]];
+        if (id < route_base) continue;                                        // block-uniform
         const uint32_t r = id - route_base;
         const uint32_t off = d.route_off[r], sz = d.route_off[r + 1] - off;
-        const uint32_t mask = d.dec[j].mask;
-        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
-            const uint32_t c = d.route_riders[off + i];
-            s_key[i] = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
-            s_inf[i] = status_of(CW_TE(d.cit[c]), s, d.exposed_time, d.infected_time) == ESIM_INFECTED ? 1 : 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            if (!d.vec[(size_t)v * FREE_MAX + j]) continue;                   // block-uniform: no infected rider in this step
+            const uint32_t s = t0 + j, mask = sm.dec[j].mask;
+            for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
+                const uint32_t c = d.route_riders[off + i];
+                sm.s_key[i] = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
+                sm.s_inf[i] = status_of(CW_TE(d.cit[c]), s, d.exposed_time, d.infected_time) == ESIM_INFECTED ? 1 : 0;
+            }
+            for (uint32_t i = threadIdx.x; i < sz / d.bus_capacity + 1u; i += TPB) sm.s_cnt[i] = 0u;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
+                const uint32_t ki = sm.s_key[i];
+                uint32_t rank = 0;
+                for (uint32_t q = 0; q < sz; ++q) { const uint32_t kq = sm.s_key[q]; rank += kq < ki || (kq == ki && q < i); }
+                const uint32_t bus = rank / d.bus_capacity;
+                sm.s_bus[i] = (uint16_t)bus;
+                if (sm.s_inf[i]) atomicAdd(&sm.s_cnt[bus], 1u);
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
+                const uint32_t k = sm.s_cnt[sm.s_bus[i]];
+                if (!k) continue;
+                const uint32_t c = d.route_riders[off + i];
+                const uint32_t w = d.cit[c], te = CW_TE(w);
+                if (w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_FLAGS)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE)) continue;   // exposed before this bus
+                const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
+                if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
+            }
+            __syncthreads();
         }
-        for (uint32_t i = threadIdx.x; i < sz / d.bus_capacity + 1u; i += TPB) s_cnt[i] = 0u;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
-            const uint32_t ki = s_key[i];
-            uint32_t rank = 0;
-            for (uint32_t q = 0; q < sz; ++q) { const uint32_t kq = s_key[q]; rank += kq < ki || (kq == ki && q < i); }
-            const uint32_t bus = rank / d.bus_capacity;
-            s_bus[i] = (uint16_t)bus;
-            if (s_inf[i]) atomicAdd(&s_cnt[bus], 1u);
+    }
+}
+
+// The deferred units of long member lists: wavefronts take them from a shared counter.
+__global__ __launch_bounds__(TPB) void k_chunk_units(Dev d, uint32_t t0, uint32_t n)
+{
+    __shared__ ChunkShared sm;
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t n_units = ld(&ctrl->n_units);
+    if (n_units == 0) return;
+    for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
+    for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, u = lane & 7u, g = lane >> 3;
+    for (;;) {
+        uint32_t q = 0;
+        if (lane == 0) q = atomicAdd(&ctrl->unit_next, 1u);
+        q = __shfl(q, 0, 64);
+        if (q >= n_units || q >= d.units_cap) break;
+        const uint32_t code = d.unit_item[q], v = code & 0x3FFFFFFFu, kind = code >> 30, lo = d.unit_lo[q];
+        const uint32_t id = (uint32_t)d.hkey[d.hitems[v]];
+        uint32_t cnt12[12], sch12[12];
+        uint32_t hi, v_sch = 0xFFFFFFFFu;
+        const uint32_t *idx;
+        if (kind == 2u) { const uint32_t r = id - d.n_bld; hi = d.room_off[r + 1]; idx = d.room_idx; v_sch = item_find(d, d.room_bld[r]); }
+        else if (kind == 1u) { hi = d.wrk_off[id + 1]; idx = d.wrk_idx; }
+        else { hi = d.res_off[id + 1]; idx = d.res_idx; }
+        if (hi > lo + UNIT_MEMBERS) hi = lo + UNIT_MEMBERS;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            cnt12[i] = d.vec[(size_t)v * FREE_MAX + g + 8u * i];
+            sch12[i] = v_sch != 0xFFFFFFFFu ? d.vec[(size_t)v_sch * FREE_MAX + g + 8u * i] : 0u;
         }
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
-            const uint32_t k = s_cnt[s_bus[i]];
-            if (!k) continue;
-            const uint32_t c = d.route_riders[off + i];
-            const uint32_t w = d.cit[c], te = CW_TE(w);
-            if (w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_FLAGS)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE)) continue;   // exposed before this bus
-            if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < threshold(d, w, mask, k)) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
-        }
-        __syncthreads();
+        member_list_wave(d, ctrl, sm, idx, lo, hi, u, g, kind, cnt12, sch12, t0, n);
     }
 }
 
@@ -781,10 +929,8 @@ __global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d, uint32_t t0)
         const uint32_t te = CW_TE(d.cit[m]);
         d.log[d.log_off[te] + atomicAdd(&d.cursor[te - TE_BIAS - t0], 1u)] = m;
     }
-    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_items; i += gridDim.x * TPB) {
-        const uint32_t h = d.hitems[i];
-        d.hkey[h] = HKEY_EMPTY; d.hcnt[h] = 0u;
-    }
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_items * FREE_MAX; i += gridDim.x * TPB) d.vec[i] = 0u;
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_items; i += gridDim.x * TPB) { const uint32_t h = d.hitems[i]; d.hkey[h] = HKEY_EMPTY; d.hval[h] = HVAL_PENDING; }
 }
 
 // ----------------------------------------------------------------------------- k_batch_finish
