@@ -329,6 +329,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         d.units_cap = (uint32_t)std::min<size_t>((size_t)N / 8u + 1024u, 1u << 26);
         if ((rc = dev_alloc(c, &d.unit_item, d.units_cap))) return rc;
         if ((rc = dev_alloc(c, &d.unit_lo, d.units_cap))) return rc;
+        if ((rc = dev_alloc(c, &d.route_pairs, d.items_cap))) return rc;
         HIP_TRY(c, hipMemset(d.hval, 0xFF, sizeof(uint32_t) * cap));
         if ((rc = dev_alloc(c, &d.newexp, (size_t)N + 1))) return rc;
         if ((rc = dev_alloc(c, &d.cursor, FREE_MAX))) return rc;

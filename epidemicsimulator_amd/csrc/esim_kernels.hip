@@ -501,67 +501,131 @@ __global__ __launch_bounds__(FIN_TPB) void k_future(Dev d, uint32_t n_ahead)
     }
 }
 
+// Highest set bit index of m, -1 when m == 0.
+__device__ __forceinline__ int top_bit(unsigned long long m) { return m ? 63 - __clzll((long long)m) : -1; }
+
+// (g after f) for transition functions on the three mask states, two bits per state.
+__device__ __forceinline__ uint32_t mask_compose(uint32_t g, uint32_t f)
+{
+    return ((g >> (2u * (f & 3u))) & 3u) | (((g >> (2u * ((f >> 2) & 3u))) & 3u) << 2) | (((g >> (2u * ((f >> 4) & 3u))) & 3u) << 4);
+}
+
 __global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t n_ahead, int allow_parallel)
 {
-    // one wavefront: lane l evaluates the threshold tests of steps l and 64 + l (interventions.rs:116-170, all
-    // strict), __ballot packs them into wave-uniform bit masks, and the state machine then walks the steps with
-    // scalar bit tests only; every lane keeps the decisions of its own two steps
+    // One wavefront, no serial loop.  Lane l evaluates the (strict) threshold tests of steps l and 64 + l
+    // (interventions.rs:116-170).  Then, per step j of the chunk:
+    //   lockdown in force      = the lockdown test of step j - 1                     (interventions.rs:116-128)
+    //   at_work / bus_dir      = set by the last step <= j that ran its schedule arm  (citizen.rs:176-206: a locked-down
+    //                            step runs none), found with ballots and count-leading-zeros
+    //   mask status in force   = the three-state machine of interventions.rs:142-180 applied to steps 0..j-1: an
+    //                            exclusive scan of transition functions under composition
     Ctrl *ctrl = d.ctrl;
     const uint32_t lane = threadIdx.x;
+    const uint32_t t0 = ctrl->t;
     const uint32_t lim_in = n_ahead < FREE_MAX ? n_ahead : FREE_MAX;
-    unsigned long long m_vacc[2], m_lock[2], m_pt_up[2], m_pt_dn[2], m_all_up[2], m_all_dn[2];
+    const bool ok = !ctrl->have_elig && !ctrl->vacc_active && !ctrl->finished && !ctrl->error && ctrl->free_base == t0;
+    const uint32_t lock_init = ctrl->lockdown, mask_init = ctrl->mask, work_init = ctrl->at_work, bus_init = ctrl->bus_dir;
+    unsigned long long m_vacc[2], m_lock[2];
+    uint32_t f_mask[2];                                   // transition function of the lane's step in each round
+    bool in[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const uint32_t j = 64u * r + lane;
-        const bool in = j < lim_in;
-        const double x = in ? (double)d.xf[j] / (double)d.n_global : 0.0;   // infected_percentage, statistics.rs:252
-        m_vacc[r] = __ballot(in && d.thr_vacc < x);
-        m_lock[r] = __ballot(in && d.thr_lockdown < x);
-        m_pt_up[r] = __ballot(in && d.thr_mask_pt < x);
-        m_pt_dn[r] = __ballot(in && x < d.thr_mask_pt);
-        m_all_up[r] = __ballot(in && d.thr_mask_all < x);
-        m_all_dn[r] = __ballot(in && x < d.thr_mask_all);
+        in[r] = j < lim_in && t0 + j <= d.max_steps;
+        const double x = in[r] ? (double)d.xf[j] / (double)d.n_global : 0.0;   // infected_percentage, statistics.rs:252
+        m_vacc[r] = __ballot(in[r] && d.thr_vacc < x);
+        m_lock[r] = __ballot(in[r] && d.thr_lockdown < x);
+        const uint32_t from_none = (in[r] && d.thr_mask_pt < x) ? 1u : 0u;
+        const uint32_t from_pt = !in[r] ? 1u : (x < d.thr_mask_pt ? 0u : (d.thr_mask_all < x ? 2u : 1u));
+        const uint32_t from_all = (in[r] && x < d.thr_mask_all) ? 1u : 2u;
+        f_mask[r] = from_none | (from_pt << 2) | (from_all << 4);
     }
-    const uint32_t t0 = ctrl->t;
-    uint32_t lockdown = ctrl->lockdown, mask = ctrl->mask, at_work = ctrl->at_work, bus_dir = ctrl->bus_dir;
-    const bool ok = !ctrl->have_elig && !ctrl->vacc_active && !ctrl->finished && !ctrl->error && ctrl->free_base == t0;
-    Decision mine0 = { 0u, 0u, 0u, 0u }, mine1 = { 0u, 0u, 0u, 0u };
+    // steps before the one that starts the vaccination programme
     uint32_t n_ok = 0;
-    uint32_t h = t0 % 24u;
-    const uint32_t lim = ok ? lim_in : 0u;
-    for (uint32_t j = 0; j < lim && t0 + j <= d.max_steps; ++j) {
-        const uint32_t r = j >> 6;
-        const unsigned long long bit = 1ull << (j & 63u);
-        if (m_vacc[r] & bit) break;                                       // this step starts the programme: not part of the chunk
-        if (!lockdown) {                                                  // citizen.rs:176-206
-            if (h == d.start_hour - 1u) bus_dir = 1u;
-            else if (h == d.start_hour) { at_work = 1u; bus_dir = 0u; }
-            else if (h == d.end_hour - 1u) bus_dir = 2u;
-            else if (h == d.end_hour) { at_work = 0u; bus_dir = 0u; }
-            else bus_dir = 0u;
-        }
-        h = h == 23u ? 0u : h + 1u;
-        const Decision q = { lockdown, mask, at_work, bus_dir };
-        if (j == lane) mine0 = q;
-        if (j == 64u + lane) mine1 = q;
-        lockdown = (m_lock[r] & bit) ? 1u : 0u;                           // interventions.rs:116-128
-        if (mask == ESIM_MASK_NONE) { if (m_pt_up[r] & bit) mask = ESIM_MASK_PUBLIC_TRANSPORT; }     // :142-180
-        else if (mask == ESIM_MASK_PUBLIC_TRANSPORT) {
-            if (m_pt_dn[r] & bit) mask = ESIM_MASK_NONE;
-            else if (m_all_up[r] & bit) mask = ESIM_MASK_EVERYWHERE;
-        } else if (m_all_dn[r] & bit) mask = ESIM_MASK_PUBLIC_TRANSPORT;
-        n_ok = j + 1u;
+    if (ok) {
+        const unsigned long long valid0 = __ballot(in[0]), valid1 = __ballot(in[1]);
+        const uint32_t n_valid = (uint32_t)(__popcll(valid0) + __popcll(valid1));
+        const uint32_t first_v = m_vacc[0] ? (uint32_t)__ffsll((long long)m_vacc[0]) - 1u : (m_vacc[1] ? 64u + (uint32_t)__ffsll((long long)m_vacc[1]) - 1u : n_valid);
+        n_ok = first_v < n_valid ? first_v : n_valid;
     }
-    const Decision after = { lockdown, mask, at_work, bus_dir };          // what is in force after the chunk
-    if (lane < n_ok) d.dec[lane] = mine0;
-    if (64u + lane < n_ok) d.dec[64u + lane] = mine1;
-    if (lane == (n_ok & 63u)) d.dec[n_ok] = after;
+    // exclusive scan of the mask transition functions (identity = 0b100100)
+    uint32_t pre[2];
+    uint32_t carry = 0x24u;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        uint32_t incl = f_mask[r];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o, 64); if (lane >= (uint32_t)o) incl = mask_compose(incl, y); }
+        uint32_t excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 0x24u;
+        pre[r] = mask_compose(excl, carry);               // everything before this step, earlier round first
+        carry = mask_compose(__shfl(incl, 63, 64), carry);
+    }
+    const Decision none = { 0u, 0u, 0u, 0u };
+    Decision mine[2] = { none, none };
+    unsigned long long run_mask[2];                       // steps that run their schedule arm (not locked down)
+    uint32_t lockd[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t j = 64u * r + lane;
+        const bool prev_lock = j == 0 ? lock_init != 0u : (j == 64u ? ((m_lock[0] >> 63) & 1ull) != 0ull : ((m_lock[r] >> (lane - 1u)) & 1ull) != 0ull);
+        lockd[r] = prev_lock ? 1u : 0u;
+        run_mask[r] = __ballot(!prev_lock);
+    }
+    // at_work and bus_dir: last deciding step at or before j, over both rounds
+    unsigned long long s1[2], s0[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t h = (t0 + 64u * r + lane) % 24u;
+        s1[r] = __ballot(!lockd[r] && h == d.start_hour);
+        s0[r] = __ballot(!lockd[r] && h == d.end_hour);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const unsigned long long le = lane == 63u ? ~0ull : ((1ull << (lane + 1u)) - 1ull);
+        // position: the latest "starts work" / "goes home" arm among the steps that ran
+        int last1 = top_bit(s1[r] & le), last0 = top_bit(s0[r] & le);
+        if (r == 1) { last1 = last1 >= 0 ? last1 + 64 : top_bit(s1[0]); last0 = last0 >= 0 ? last0 + 64 : top_bit(s0[0]); }
+        const uint32_t at_work = last1 > last0 ? 1u : (last0 > last1 ? 0u : work_init);
+        // bus: the latest step that ran any arm decides (every arm assigns on_public_transport)
+        int last_run = top_bit(run_mask[r] & le);
+        if (r == 1) last_run = last_run >= 0 ? last_run + 64 : top_bit(run_mask[0]);
+        uint32_t bus_dir = bus_init;
+        if (last_run >= 0) {
+            const uint32_t hh = (t0 + (uint32_t)last_run) % 24u;
+            bus_dir = hh == d.start_hour - 1u ? 1u : (hh == d.end_hour - 1u ? 2u : 0u);
+        }
+        const uint32_t msk = (pre[r] >> (2u * mask_init)) & 3u;
+        mine[r] = Decision{ lockd[r], msk, at_work, bus_dir };
+    }
+    // what is in force after the chunk = what would be in force during step n_ok, except that position and bus
+    // are those of step n_ok - 1 (k_batch_finish reads them from there)
+    if (lane < n_ok) d.dec[lane] = mine[0];
+    if (64u + lane < n_ok) d.dec[64u + lane] = mine[1];
+    {
+        // entry n_ok: lockdown / mask after the last step of the chunk; computed by the lane that owns step n_ok when
+        // it exists in the arrays, else from the scan totals
+        const uint32_t jn = n_ok;
+        uint32_t lock_after, mask_after;
+        if (jn == 0) { lock_after = lock_init; mask_after = mask_init; }
+        else {
+            const uint32_t jl = jn - 1u;                                  // last step of the chunk
+            lock_after = (uint32_t)((m_lock[jl >> 6] >> (jl & 63u)) & 1ull);
+            // mask after step jl = f_jl applied to the mask in force during jl
+            const uint32_t f_last = __shfl(jl < 64u ? f_mask[0] : f_mask[1], (int)(jl & 63u), 64);
+            const uint32_t pre_last = __shfl(jl < 64u ? pre[0] : pre[1], (int)(jl & 63u), 64);
+            mask_after = (mask_compose(f_last, pre_last) >> (2u * mask_init)) & 3u;
+        }
+        const uint32_t aw_last = jn ? __shfl(jn - 1u < 64u ? mine[0].at_work : mine[1].at_work, (int)((jn - 1u) & 63u), 64) : work_init;
+        const uint32_t bd_last = jn ? __shfl(jn - 1u < 64u ? mine[0].bus_dir : mine[1].bus_dir, (int)((jn - 1u) & 63u), 64) : bus_init;
+        if (lane == 0) d.dec[jn] = Decision{ lock_after, mask_after, aw_last, bd_last };
+    }
     if (lane == 0) {
         ctrl->chunk_ok = n_ok;
         // a citizen marks at most its home, its work building, its room and its route
         ctrl->chunk_parallel = (allow_parallel && d.items_cap && d.max_route <= CHUNK_ROUTE_MAX &&
-                                (unsigned long long)ctrl->chunk_pairs * 4ull <= (unsigned long long)d.items_cap) ? 1u : 0u;
-        ctrl->n_items = 0u; ctrl->n_newexp = 0u; ctrl->n_units = 0u; ctrl->unit_next = 0u;
+                                (unsigned long long)ctrl->chunk_pairs * 4ull + 65536ull <= (unsigned long long)d.items_cap) ? 1u : 0u;
+        ctrl->n_items = 0u; ctrl->n_newexp = 0u; ctrl->n_units = 0u; ctrl->unit_next = 0u; ctrl->n_route_pairs = 0u;
     }
     d.cursor[lane] = 0u;
     if (lane < FREE_MAX - 64u) d.cursor[64u + lane] = 0u;
@@ -598,38 +662,41 @@ __global__ __launch_bounds__(TPB) void k_pipe(Dev d, uint32_t t, uint32_t j, uin
 // its draws succeeds (later draws would have been skipped by `is_susceptible()`, simulator.rs:337), and within a
 // step a building exposure precedes a bus exposure (simulator.rs:268-401).  With the exposure step in the top
 // bits of the citizen word and the bus bit right below, that is one atomicMin per successful draw -- so all
-// steps of the chunk are drawn in ONE pass over the (marked item, step) pairs.
+// steps of the chunk are drawn in ONE pass.
+//   k_chunk_marks  an item per building / room / route that somebody Infected stands in during the chunk, with
+//                  the number of Infected standing there in each of its steps (generate_exposures)
+//   k_chunk_draw   the (member, marked step) pairs of every item, densely over the lanes (apply_exposures)
+//   k_chunk_units  the same for member lists too long for one wavefront
+//   k_chunk_count, k_batch_finish, k_chunk_scatter   exposure counts, books, log entries
 __device__ __forceinline__ uint32_t hash64(unsigned long long k)
 {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
     return (uint32_t)k;
 }
 
-// Item of `key` (a building, a room or a route that somebody Infected stands in during the chunk), claimed if the
-// key is new.  Two phases, so that a wavefront has published ALL its own claims before any of its lanes waits:
-// item_claim probes without ever waiting -- the claimer allocates the index and publishes it; item_wait is called
-// after the lanes have reconverged by those that found the key already there, and waits (bounded) for the index.
-// The claimer it waits for sits in a wavefront that is past its own item_claim or inside it, never in item_wait.
+// Items live in an open-addressing hash map keyed by slot id (building | n_bld + room | n_bld + n_room + route).
+// Claiming is two-phase so that a wavefront has published ALL its own claims before any of its lanes waits:
+// item_probe never waits; the claiming lanes then take indices from their wavefront's pool (ITEM_POOL indices per
+// global atomic -- one counter bumped once per claim would serialise the pass) and publish them; item_wait is
+// called after the lanes have reconverged by those that found the key already there, and waits (bounded) for the
+// index.  The claimer it waits for sits in a wavefront that is still probing or already past its claims -- never
+// itself waiting with an unpublished claim.
 #define HVAL_PENDING 0xFFFFFFFFu
-__device__ __forceinline__ uint32_t item_claim(const Dev &d, Ctrl *ctrl, unsigned long long key, uint32_t &slot, bool &pending)
+#define ITEM_POOL 8u
+#define ITEM_UNUSED 0xFFFFFFFFu
+__device__ __forceinline__ bool item_probe(const Dev &d, Ctrl *ctrl, unsigned long long key, uint32_t &slot, bool &pending)
 {
     uint32_t h = hash64(key) & (d.hcap - 1u);
     pending = false;
     for (uint32_t probe = 0; probe < d.hcap; ++probe) {
         const unsigned long long old = atomicCAS(&d.hkey[h], HKEY_EMPTY, key);
-        if (old == HKEY_EMPTY) {
-            uint32_t v = atomicAdd(&ctrl->n_items, 1u);
-            if (v >= d.items_cap) { ctrl->error = (uint32_t)(-ESIM_ERANGE); v = 0u; } else d.hitems[v] = h;
-            __hip_atomic_store(&d.hval[h], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            slot = h;
-            return v;
-        }
-        if (old == key) { slot = h; pending = true; return 0u; }
+        if (old == HKEY_EMPTY) { slot = h; return true; }
+        if (old == key) { slot = h; pending = true; return false; }
         h = (h + 1u) & (d.hcap - 1u);
     }
     ctrl->error = (uint32_t)(-ESIM_ERANGE);
     slot = 0u;
-    return 0u;
+    return false;
 }
 
 __device__ __forceinline__ uint32_t item_wait(const Dev &d, Ctrl *ctrl, uint32_t slot)
@@ -656,8 +723,8 @@ __device__ __forceinline__ uint32_t item_find(const Dev &d, unsigned long long k
     return 0xFFFFFFFFu;
 }
 
-// Where an Infected citizen stands in step t0 + j of the chunk (simulator.rs:181-198): bit 0 in the home
-// building, bit 1 in the work building, bit 2 on the bus.  0 when not Infected in that step.
+// Where an Infected citizen stands in step s of the chunk (simulator.rs:181-198): bit 0 in the home building,
+// bit 1 in the work building, bit 2 on the bus.  0 when not Infected in that step.
 __device__ __forceinline__ uint32_t where_in_step(const Dev &d, uint32_t w, uint32_t s, const Decision &q)
 {
     if (status_of(CW_TE(w), s, d.exposed_time, d.infected_time) != ESIM_INFECTED) return 0u;
@@ -665,8 +732,8 @@ __device__ __forceinline__ uint32_t where_in_step(const Dev &d, uint32_t w, uint
     return (q.at_work && (w & FL_HAS_WORK)) ? 2u : 1u;
 }
 
-// generate_exposures (simulator.rs:181-198) for every step of the chunk: one wavefront per citizen
-// that is Infected somewhere in the chunk; lanes are the steps.
+// generate_exposures (simulator.rs:181-198) for every step of the chunk: one wavefront per citizen that is
+// Infected somewhere in the chunk; lanes are the steps (two rounds of 64).
 __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d, uint32_t t0, uint32_t n)
 {
     Ctrl *ctrl = d.ctrl;
@@ -689,6 +756,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d, uint32_t t0, uint32_
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
     const Decision q0 = lane < n ? d.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
     const Decision q1 = 64u + lane < n ? d.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
+    uint32_t pool_next = 0, pool_left = 0;
     for (uint32_t e = i0 + wave; e < i1; e += n_waves) {
         const uint32_t c = d.log[e];
         const uint32_t w = d.cit[c];
@@ -704,8 +772,25 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d, uint32_t t0, uint32_
         if (lane == 2 && any_work && school) key = (unsigned long long)d.n_bld + d.room[c];
         if (lane == 3 && any_bus) key = (unsigned long long)d.n_bld + d.n_room + d.route_of[c];
         uint32_t v = 0xFFFFFFFFu, slot = 0u;
-        bool pending = false;
-        if (key != HKEY_EMPTY) v = item_claim(d, ctrl, key, slot, pending);   // every claim of this wavefront is published here ...
+        bool pending = false, claimed = false;
+        if (key != HKEY_EMPTY) claimed = item_probe(d, ctrl, key, slot, pending);
+        const unsigned long long cm = __ballot(claimed);
+        if (cm) {
+            const uint32_t need = (uint32_t)__popcll(cm);
+            if (pool_left < need) {                                           // wave-uniform
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&ctrl->n_items, ITEM_POOL);
+                pool_next = __shfl(base, 0, 64); pool_left = ITEM_POOL;
+                if (pool_next + ITEM_POOL > d.items_cap) { ctrl->error = (uint32_t)(-ESIM_ERANGE); pool_next = 0u; }
+                else if (lane < ITEM_POOL) d.hitems[pool_next + lane] = ITEM_UNUSED;
+            }
+            if (claimed) {
+                v = pool_next + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
+                d.hitems[v] = slot;
+                __hip_atomic_store(&d.hval[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // claims are published here ...
+            }
+            pool_next += need; pool_left -= need;
+        }
         __builtin_amdgcn_wave_barrier();
         if (pending) v = item_wait(d, ctrl, slot);                            // ... before any lane waits for somebody else's
         const uint32_t v_home = __shfl(v, 0, 64), v_work = __shfl(v, 1, 64), v_room = __shfl(v, 2, 64), v_bus = __shfl(v, 3, 64);
@@ -713,18 +798,18 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d, uint32_t t0, uint32_
         if (p1 & 1u) atomicAdd(&d.vec[(size_t)v_home * FREE_MAX + 64u + lane], 1u);
         if (p0 & 2u) { atomicAdd(&d.vec[(size_t)v_work * FREE_MAX + lane], 1u); if (school) atomicAdd(&d.vec[(size_t)v_room * FREE_MAX + lane], 1u); }
         if (p1 & 2u) { atomicAdd(&d.vec[(size_t)v_work * FREE_MAX + 64u + lane], 1u); if (school) atomicAdd(&d.vec[(size_t)v_room * FREE_MAX + 64u + lane], 1u); }
-        if (p0 & 4u) atomicAdd(&d.vec[(size_t)v_bus * FREE_MAX + lane], 1u);
-        if (p1 & 4u) atomicAdd(&d.vec[(size_t)v_bus * FREE_MAX + 64u + lane], 1u);
+        // the first Infected rider of a (route, step) registers the pair: each gets a workgroup of its own in k_chunk_draw
+        if ((p0 & 4u) && atomicAdd(&d.vec[(size_t)v_bus * FREE_MAX + lane], 1u) == 0u) append(d.route_pairs, &ctrl->n_route_pairs, (v_bus << 7) | lane);
+        if ((p1 & 4u) && atomicAdd(&d.vec[(size_t)v_bus * FREE_MAX + 64u + lane], 1u) == 0u) append(d.route_pairs, &ctrl->n_route_pairs, (v_bus << 7) | (64u + lane));
     }
 }
 
-// A successful draw of citizen m in step s (bus: on public transport).  Returns the word the citizen has now.
-__device__ __forceinline__ uint32_t expose_min(const Dev &d, Ctrl *ctrl, uint32_t m, uint32_t w, uint32_t s, uint32_t bus)
+// A successful draw of citizen m in step s (bus: on public transport).
+__device__ __forceinline__ void expose_min(const Dev &d, Ctrl *ctrl, uint32_t m, uint32_t w, uint32_t s, uint32_t bus)
 {
     const uint32_t cand = CW_MAKE(s + TE_BIAS, bus | (w & CW_FLAGS));
     const uint32_t prev = atomicMin(&d.cit[m], cand);
     if (cand < prev && CW_TE(prev) == TE_SUSCEPTIBLE) append(d.newexp, &ctrl->n_newexp, m);   // first exposure in this chunk
-    return cand < prev ? cand : prev;
 }
 
 struct ChunkShared {
@@ -735,59 +820,79 @@ struct ChunkShared {
     uint8_t s_inf[CHUNK_ROUTE_MAX];
     uint32_t s_cnt[CHUNK_ROUTE_MAX + 1];
 };
+struct WaveScratch { uint32_t cnt[FREE_MAX]; uint32_t sch[FREE_MAX]; uint8_t steps[FREE_MAX]; };
 
-// One member list of one item, all steps of the chunk, by one wavefront: lane = member slot u (0..7) + 8 * step
-// residue g (0..7); a lane draws for its member in the steps g, g + 8, ..., g + 88 in which somebody Infected stands
-// in the item (cnt12 / sch12: the item's and the school's counts of those twelve steps).  No ordering is needed
-// between steps or lists: every successful draw is one atomicMin.  kind 0 residents, 1 workers, 2 room participants.
-__device__ __forceinline__ void member_list_wave(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, const uint32_t *idx,
-                                                 uint32_t lo, uint32_t hi, uint32_t u, uint32_t g, uint32_t kind,
-                                                 const uint32_t (&cnt12)[12], const uint32_t (&sch12)[12], uint32_t t0, uint32_t n)
+// One member list of one item over the marked steps of the chunk: the (member, marked step) pairs [p_lo, p_hi) are
+// spread densely over the 64 lanes (the draws are Philox-bound -- 20 quarter-rate multiplies each -- so idle lanes
+// are what costs).  ws.steps: the item's marked steps in order, S of them; ws.cnt / ws.sch: the item's / the school's
+// Infected per step.  kind 0 residents, 1 workers, 2 room participants.
+__device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, const WaveScratch &ws, const uint32_t *idx,
+                                             uint32_t lo, uint32_t p_lo, uint32_t p_hi, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0)
 {
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
-    for (uint32_t q = lo + u; q < hi; q += 8u) {
-        const uint32_t m = idx ? idx[q] : q;
-        uint32_t w = d.cit[m];
-        const uint32_t te0 = CW_TE(w);
-        if (te0 >= TE_RECOVERED && te0 != TE_SUSCEPTIBLE) continue;
-        const uint32_t gid = d.id_base + m;
+    for (uint32_t p = p_lo + lane; p < p_hi; p += 64u) {
+        const uint32_t um = p / S, j = ws.steps[p - um * S];
+        const uint32_t m = idx ? idx[lo + um] : lo + um;
+        const uint32_t w = d.cit[m];
+        const uint32_t te = CW_TE(w), s = t0 + j;
+        if (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) continue;
+        // Susceptible when this list is walked in step s: never exposed, or so far only exposed by something that
+        // comes later (a later step, or a bus of this step) -- that exposure may be undercut
+        if (w <= CW_MAKE(s + TE_BIAS, w & CW_FLAGS)) continue;
+        const uint32_t at_work = sm.dec[j].at_work, mask = sm.dec[j].mask;
         const bool same = w & FL_SAME_AREA;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const uint32_t j = g + 8u * i;
-            const uint32_t cnt = cnt12[i];
-            if (j >= n || !cnt) continue;
-            const uint32_t s = t0 + j;
-            // Susceptible when this list is walked in step s: never exposed, or so far only exposed by something that
-            // comes later (a later step, or a bus of this step) -- that exposure may be undercut
-            if (w <= CW_MAKE(s + TE_BIAS, w & CW_FLAGS)) continue;
-            const uint32_t at_work = sm.dec[j].at_work, mask = sm.dec[j].mask;
-            if (kind == 0u) { if (at_work && (w & FL_HAS_WORK) && !same) continue; }       // simulator.rs:324
-            else if (!at_work && !same) continue;
-            const uint32_t nn = kind == 2u ? sch12[i] : cnt;                                // exposure_count: infected in the building
-            const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
-            const uint64_t thr = sm.thr[row * 256u + (nn & 255u)];
-            bool hit = false;
-            if (kind == 2u) { for (uint32_t k = 0; k < cnt && !hit; ++k) hit = esim_u53(seed, gid, s, ESIM_SLOT_ROOM0 + k) < thr; }
-            else hit = esim_u53(seed, gid, s, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK) < thr;
-            if (hit) w = expose_min(d, ctrl, m, w, s, 0u);
-        }
+        if (kind == 0u) { if (at_work && (w & FL_HAS_WORK) && !same) continue; }           // simulator.rs:324
+        else if (!at_work && !same) continue;
+        const uint32_t cnt = ws.cnt[j];
+        const uint32_t nn = kind == 2u ? ws.sch[j] : cnt;                                   // exposure_count: infected in the building
+        const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
+        const uint64_t thr = sm.thr[row * 256u + (nn & 255u)];
+        const uint32_t gid = d.id_base + m;
+        bool hit = false;
+        if (kind == 2u) { for (uint32_t k = 0; k < cnt && !hit; ++k) hit = esim_u53(seed, gid, s, ESIM_SLOT_ROOM0 + k) < thr; }
+        else hit = esim_u53(seed, gid, s, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK) < thr;
+        if (hit) expose_min(d, ctrl, m, w, s, 0u);
     }
 }
 
-// Long member lists are cut into units of UNIT_MEMBERS members that any wavefront can take (k_chunk_units), so that
-// one 200-member workplace does not keep a single wavefront busy while the chip idles.
-#define UNIT_MEMBERS 16u
-__device__ __forceinline__ void defer_units(const Dev &d, Ctrl *ctrl, uint32_t v, uint32_t kind, uint32_t lo, uint32_t hi, uint32_t lane)
+// The marked steps of item v, in order, and its per-step counts, into this wavefront's scratch.  Returns S.
+__device__ __forceinline__ uint32_t item_steps(const Dev &d, uint32_t v, uint32_t lane, uint32_t n, WaveScratch &ws)
 {
-    const uint32_t n_units = (hi - lo + UNIT_MEMBERS - 1u) / UNIT_MEMBERS;
+    const uint32_t c0 = lane < n ? d.vec[(size_t)v * FREE_MAX + lane] : 0u;
+    const uint32_t c1 = 64u + lane < n ? d.vec[(size_t)v * FREE_MAX + 64u + lane] : 0u;
+    ws.cnt[lane] = c0;
+    if (lane < FREE_MAX - 64u) ws.cnt[64u + lane] = c1;
+    const unsigned long long b0 = __ballot(c0 != 0u), b1 = __ballot(c1 != 0u);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (c0) ws.steps[__popcll(b0 & lt)] = (uint8_t)lane;
+    if (c1) ws.steps[__popcll(b0) + __popcll(b1 & lt)] = (uint8_t)(64u + lane);
+    return (uint32_t)(__popcll(b0) + __popcll(b1));
+}
+
+__device__ __forceinline__ void school_counts(const Dev &d, uint32_t room, uint32_t lane, uint32_t n, WaveScratch &ws)
+{
+    const uint32_t v_sch = item_find(d, d.room_bld[room]);                    // infected in the whole school, per step
+    ws.sch[lane] = (v_sch != 0xFFFFFFFFu && lane < n) ? d.vec[(size_t)v_sch * FREE_MAX + lane] : 0u;
+    if (lane < FREE_MAX - 64u) ws.sch[64u + lane] = (v_sch != 0xFFFFFFFFu && 64u + lane < n) ? d.vec[(size_t)v_sch * FREE_MAX + 64u + lane] : 0u;
+}
+
+// Lists with more pairs than this are cut into units that any wavefront can take (k_chunk_units), so that one
+// 200-member workplace does not keep a single wavefront busy while the chip idles.
+#define UNIT_PAIRS 1024u
+__device__ __forceinline__ void list_or_units(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, const WaveScratch &ws, const uint32_t *idx,
+                                              uint32_t lo, uint32_t hi, uint32_t v, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0)
+{
+    const uint32_t pairs = (hi - lo) * S;
+    if (pairs == 0) return;
+    if (pairs <= UNIT_PAIRS) { member_pairs(d, ctrl, sm, ws, idx, lo, 0u, pairs, lane, kind, S, t0); return; }
+    const uint32_t n_units = (pairs + UNIT_PAIRS - 1u) / UNIT_PAIRS;
     uint32_t start = 0;
     if (lane == 0) start = atomicAdd(&ctrl->n_units, n_units);
     start = __shfl(start, 0, 64);
     for (uint32_t i = lane; i < n_units; i += 64u) {
         if (start + i >= d.units_cap) { ctrl->error = (uint32_t)(-ESIM_ERANGE); break; }
         d.unit_item[start + i] = v | (kind << 30);
-        d.unit_lo[start + i] = lo + i * UNIT_MEMBERS;
+        d.unit_lo[start + i] = i * UNIT_PAIRS;
     }
 }
 
@@ -795,115 +900,104 @@ __device__ __forceinline__ void defer_units(const Dev &d, Ctrl *ctrl, uint32_t v
 __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t t0, uint32_t n)
 {
     __shared__ ChunkShared sm;
+    __shared__ WaveScratch wsc[TPB / 64];
     Ctrl *ctrl = d.ctrl;
     for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
     for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
     __syncthreads();
-    const uint32_t n_items = ld(&ctrl->n_items);
-    const uint32_t lane = threadIdx.x & 63u, u = lane & 7u, g = lane >> 3;
+    const uint32_t n_items = min(ld(&ctrl->n_items), d.items_cap);
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
     const uint32_t route_base = d.n_bld + d.n_room;
+    WaveScratch &ws = wsc[threadIdx.x >> 6];
     // (1) buildings and school rooms: one wavefront per item
     for (uint32_t v = wave; v < n_items; v += n_waves) {
-        const uint32_t id = (uint32_t)d.hkey[d.hitems[v]];
+        const uint32_t hs = d.hitems[v];
+        if (hs == ITEM_UNUSED) continue;
+        const uint32_t id = (uint32_t)d.hkey[hs];
         if (id >= route_base) continue;
-        uint32_t cnt12[12], sch12[12];
         if (id < d.n_bld) {
             if (d.bld_type[id] == ESIM_SCHOOL) continue;                      // School::find_exposures works per room
-#pragma unroll
-            for (int i = 0; i < 12; ++i) { cnt12[i] = d.vec[(size_t)v * FREE_MAX + g + 8u * i]; sch12[i] = 0u; }
+            const uint32_t S = item_steps(d, v, lane, n, ws);
+            __builtin_amdgcn_wave_barrier();
             // Household / Workplace::find_exposures: every registered occupant (building.rs:202-204,278-280)
-            const uint32_t r0 = d.res_off[id], r1 = d.res_off[id + 1], w0 = d.wrk_off[id], w1 = d.wrk_off[id + 1];
-            if (r1 - r0 <= UNIT_MEMBERS) member_list_wave(d, ctrl, sm, d.res_idx, r0, r1, u, g, 0u, cnt12, sch12, t0, n);
-            else defer_units(d, ctrl, v, 0u, r0, r1, lane);
-            if (w1 - w0 <= UNIT_MEMBERS) member_list_wave(d, ctrl, sm, d.wrk_idx, w0, w1, u, g, 1u, cnt12, sch12, t0, n);
-            else defer_units(d, ctrl, v, 1u, w0, w1, lane);
+            list_or_units(d, ctrl, sm, ws, d.res_idx, d.res_off[id], d.res_off[id + 1], v, lane, 0u, S, t0);
+            list_or_units(d, ctrl, sm, ws, d.wrk_idx, d.wrk_off[id], d.wrk_off[id + 1], v, lane, 1u, S, t0);
         } else {
             const uint32_t r = id - d.n_bld;
-            const uint32_t v_sch = item_find(d, d.room_bld[r]);               // infected in the whole school, per step
-#pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                cnt12[i] = d.vec[(size_t)v * FREE_MAX + g + 8u * i];
-                sch12[i] = v_sch != 0xFFFFFFFFu ? d.vec[(size_t)v_sch * FREE_MAX + g + 8u * i] : 0u;
-            }
+            const uint32_t S = item_steps(d, v, lane, n, ws);
+            school_counts(d, r, lane, n, ws);
+            __builtin_amdgcn_wave_barrier();
             // School::find_exposures: the room once per infected in it (building.rs:494-522)
-            const uint32_t m0 = d.room_off[r], m1 = d.room_off[r + 1];
-            if (m1 - m0 <= UNIT_MEMBERS) member_list_wave(d, ctrl, sm, d.room_idx, m0, m1, u, g, 2u, cnt12, sch12, t0, n);
-            else defer_units(d, ctrl, v, 2u, m0, m1, lane);
+            list_or_units(d, ctrl, sm, ws, d.room_idx, d.room_off[r], d.room_off[r + 1], v, lane, 2u, S, t0);
         }
+        __builtin_amdgcn_wave_barrier();
     }
-    // (2) routes: one workgroup per route, its bus steps one after the other; rank by (Philox key, id) through LDS,
+    // (2) routes: one workgroup per (route, bus step) with an Infected rider; rank by (Philox key, id) through LDS,
     // buses are runs of bus_capacity ranks (simulator.rs:362-388)
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
-    for (uint32_t v = blockIdx.x; v < n_items; v += gridDim.x) {
-        const uint32_t id = (uint32_t)d.hkey[d.hitems[v]];
-        if (id < route_base) continue;                                        // block-uniform
-        const uint32_t r = id - route_base;
+    const uint32_t n_pairs = min(ld(&ctrl->n_route_pairs), d.items_cap);
+    for (uint32_t q = blockIdx.x; q < n_pairs; q += gridDim.x) {
+        const uint32_t code = d.route_pairs[q], v = code >> 7, j = code & 127u;
+        const uint32_t r = (uint32_t)d.hkey[d.hitems[v]] - route_base;
         const uint32_t off = d.route_off[r], sz = d.route_off[r + 1] - off;
-        for (uint32_t j = 0; j < n; ++j) {
-            if (!d.vec[(size_t)v * FREE_MAX + j]) continue;                   // block-uniform: no infected rider in this step
-            const uint32_t s = t0 + j, mask = sm.dec[j].mask;
-            for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
-                const uint32_t c = d.route_riders[off + i];
-                sm.s_key[i] = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
-                sm.s_inf[i] = status_of(CW_TE(d.cit[c]), s, d.exposed_time, d.infected_time) == ESIM_INFECTED ? 1 : 0;
-            }
-            for (uint32_t i = threadIdx.x; i < sz / d.bus_capacity + 1u; i += TPB) sm.s_cnt[i] = 0u;
-            __syncthreads();
-            for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
-                const uint32_t ki = sm.s_key[i];
-                uint32_t rank = 0;
-                for (uint32_t q = 0; q < sz; ++q) { const uint32_t kq = sm.s_key[q]; rank += kq < ki || (kq == ki && q < i); }
-                const uint32_t bus = rank / d.bus_capacity;
-                sm.s_bus[i] = (uint16_t)bus;
-                if (sm.s_inf[i]) atomicAdd(&sm.s_cnt[bus], 1u);
-            }
-            __syncthreads();
-            for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
-                const uint32_t k = sm.s_cnt[sm.s_bus[i]];
-                if (!k) continue;
-                const uint32_t c = d.route_riders[off + i];
-                const uint32_t w = d.cit[c], te = CW_TE(w);
-                if (w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_FLAGS)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE)) continue;   // exposed before this bus
-                const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
-                if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
-            }
-            __syncthreads();
+        const uint32_t s = t0 + j, mask = sm.dec[j].mask;
+        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
+            const uint32_t c = d.route_riders[off + i];
+            sm.s_key[i] = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
+            sm.s_inf[i] = status_of(CW_TE(d.cit[c]), s, d.exposed_time, d.infected_time) == ESIM_INFECTED ? 1 : 0;
         }
+        for (uint32_t i = threadIdx.x; i < sz / d.bus_capacity + 1u; i += TPB) sm.s_cnt[i] = 0u;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
+            const uint32_t ki = sm.s_key[i];
+            uint32_t rank = 0;
+            for (uint32_t qq = 0; qq < sz; ++qq) { const uint32_t kq = sm.s_key[qq]; rank += kq < ki || (kq == ki && qq < i); }
+            const uint32_t bus = rank / d.bus_capacity;
+            sm.s_bus[i] = (uint16_t)bus;
+            if (sm.s_inf[i]) atomicAdd(&sm.s_cnt[bus], 1u);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
+            const uint32_t k = sm.s_cnt[sm.s_bus[i]];
+            if (!k) continue;
+            const uint32_t c = d.route_riders[off + i];
+            const uint32_t w = d.cit[c], te = CW_TE(w);
+            if (w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_FLAGS)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE)) continue;   // exposed before this bus
+            const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
+            if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
+        }
+        __syncthreads();
     }
 }
 
-// The deferred units of long member lists: wavefronts take them from a shared counter.
+// The deferred units of long member lists, dealt to the wavefronts round-robin.
 __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d, uint32_t t0, uint32_t n)
 {
     __shared__ ChunkShared sm;
+    __shared__ WaveScratch wsc[TPB / 64];
     Ctrl *ctrl = d.ctrl;
-    const uint32_t n_units = ld(&ctrl->n_units);
+    const uint32_t n_units = min(ld(&ctrl->n_units), d.units_cap);
     if (n_units == 0) return;
     for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
     for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, u = lane & 7u, g = lane >> 3;
-    for (;;) {
-        uint32_t q = 0;
-        if (lane == 0) q = atomicAdd(&ctrl->unit_next, 1u);
-        q = __shfl(q, 0, 64);
-        if (q >= n_units || q >= d.units_cap) break;
-        const uint32_t code = d.unit_item[q], v = code & 0x3FFFFFFFu, kind = code >> 30, lo = d.unit_lo[q];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    WaveScratch &ws = wsc[threadIdx.x >> 6];
+    for (uint32_t q = wave; q < n_units; q += n_waves) {
+        const uint32_t code = d.unit_item[q], v = code & 0x3FFFFFFFu, kind = code >> 30, p_lo = d.unit_lo[q];
         const uint32_t id = (uint32_t)d.hkey[d.hitems[v]];
-        uint32_t cnt12[12], sch12[12];
-        uint32_t hi, v_sch = 0xFFFFFFFFu;
+        const uint32_t S = item_steps(d, v, lane, n, ws);
+        uint32_t lo, hi;
         const uint32_t *idx;
-        if (kind == 2u) { const uint32_t r = id - d.n_bld; hi = d.room_off[r + 1]; idx = d.room_idx; v_sch = item_find(d, d.room_bld[r]); }
-        else if (kind == 1u) { hi = d.wrk_off[id + 1]; idx = d.wrk_idx; }
-        else { hi = d.res_off[id + 1]; idx = d.res_idx; }
-        if (hi > lo + UNIT_MEMBERS) hi = lo + UNIT_MEMBERS;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            cnt12[i] = d.vec[(size_t)v * FREE_MAX + g + 8u * i];
-            sch12[i] = v_sch != 0xFFFFFFFFu ? d.vec[(size_t)v_sch * FREE_MAX + g + 8u * i] : 0u;
-        }
-        member_list_wave(d, ctrl, sm, idx, lo, hi, u, g, kind, cnt12, sch12, t0, n);
+        if (kind == 2u) { const uint32_t r = id - d.n_bld; lo = d.room_off[r]; hi = d.room_off[r + 1]; idx = d.room_idx; school_counts(d, r, lane, n, ws); }
+        else if (kind == 1u) { lo = d.wrk_off[id]; hi = d.wrk_off[id + 1]; idx = d.wrk_idx; }
+        else { lo = d.res_off[id]; hi = d.res_off[id + 1]; idx = d.res_idx; }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t pairs = (hi - lo) * S;
+        member_pairs(d, ctrl, sm, ws, idx, lo, p_lo, min(pairs, p_lo + UNIT_PAIRS), lane, kind, S, t0);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -918,19 +1012,22 @@ __global__ __launch_bounds__(TPB) void k_chunk_count(Dev d)
     }
 }
 
-// The chunk's exposures enter the log grouped by step (after k_batch_finish wrote the offsets); the hash map is
-// emptied for the next chunk.
+// The chunk's exposures enter the log grouped by step (after k_batch_finish wrote the offsets); the hash map and
+// the count vectors are emptied for the next chunk.
 __global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d, uint32_t t0)
 {
     Ctrl *ctrl = d.ctrl;
-    const uint32_t n_new = ld(&ctrl->n_newexp), n_items = ld(&ctrl->n_items);
+    const uint32_t n_new = ld(&ctrl->n_newexp), n_items = min(ld(&ctrl->n_items), d.items_cap);
     for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_new; i += gridDim.x * TPB) {
         const uint32_t m = d.newexp[i];
         const uint32_t te = CW_TE(d.cit[m]);
         d.log[d.log_off[te] + atomicAdd(&d.cursor[te - TE_BIAS - t0], 1u)] = m;
     }
     for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_items * FREE_MAX; i += gridDim.x * TPB) d.vec[i] = 0u;
-    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_items; i += gridDim.x * TPB) { const uint32_t h = d.hitems[i]; d.hkey[h] = HKEY_EMPTY; d.hval[h] = HVAL_PENDING; }
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_items; i += gridDim.x * TPB) {
+        const uint32_t h = d.hitems[i];
+        if (h != ITEM_UNUSED) { d.hkey[h] = HKEY_EMPTY; d.hval[h] = HVAL_PENDING; }
+    }
 }
 
 // ----------------------------------------------------------------------------- k_batch_finish

@@ -28,8 +28,10 @@ ESIM_HD philox_out philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = esim_mulhi32(M0, c0), lo0 = M0 * c0;
-        uint32_t hi1 = esim_mulhi32(M1, c2), lo1 = M1 * c2;
+        // one 32x32->64 product each (v_mad_u64_u32 on gfx950: half the quarter-rate multiplies of mul_hi + mul_lo)
+        const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c0 = hi1 ^ c1 ^ k0; c1 = lo1;
         c2 = hi0 ^ c3 ^ k1; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
