@@ -325,6 +325,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if ((rc = dev_alloc(c, &d.hkey, cap))) return rc;
         if ((rc = dev_alloc(c, &d.hval, cap))) return rc;
         if ((rc = dev_alloc(c, &d.hitems, d.items_cap))) return rc;
+        if ((rc = dev_alloc(c, &d.item_rec, d.items_cap))) return rc;
         if ((rc = dev_alloc(c, &d.vec, (size_t)d.items_cap * FREE_MAX))) return rc;
         d.units_cap = (uint32_t)std::min<size_t>((size_t)N / 8u + 1024u, 1u << 26);
         if ((rc = dev_alloc(c, &d.unit_item, d.units_cap))) return rc;
@@ -574,13 +575,26 @@ int run_sequential(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, ui
     return ESIM_OK;
 }
 
+// The kernels of one time-parallel chunk; they take the chunk (first step, length, whether it may run this way)
+// from the control block as k_decide left it, and do nothing when it may not.
+void enqueue_parallel_chunk(esim_ctx_impl *c)
+{
+    Dev &d = c->d;
+    hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_finish, dim3(1), dim3(FIN_TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d);
+}
+
 // One pipelined chunk.  Precondition: k_future ran for the current step (and, when sharded, buffer F was
 // all-reduced).  k_decide finds how many of the next n_ahead steps can run before a vaccination programme
 // would start; those run as one k_pipe each and k_batch_finish writes their books.  *executed = steps run.
 int run_chunk(esim_ctx_impl *c, uint32_t n_ahead, uint32_t *executed, Ctrl *state_before)
 {
     Dev &d = c->d;
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, n_ahead, c->time_parallel ? 1 : 0);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, n_ahead, c->P.max_steps, c->time_parallel ? 1 : 0);
     Ctrl h;
     HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -593,12 +607,7 @@ int run_chunk(esim_ctx_impl *c, uint32_t n_ahead, uint32_t *executed, Ctrl *stat
         // every step of the chunk in one pass: marks of all steps, draws of all (item, step) pairs, then the books
         const bool tk = c->kernel_timing;
         if (tk) { if (!c->cev[0]) { (void)hipEventCreate(&c->cev[0]); (void)hipEventCreate(&c->cev[1]); } HIP_TRY(c, hipEventRecord(c->cev[0], c->stream)); }
-        hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d, t0, n);
-        hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d, t0, n);
-        hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d, t0, n);
-        hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);
-        hipLaunchKernelGGL(k_batch_finish, dim3(1), dim3(FIN_TPB), 0, c->stream, d, t0, n);
-        hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d, t0);
+        enqueue_parallel_chunk(c);
         if (tk) { HIP_TRY(c, hipEventRecord(c->cev[1], c->stream)); HIP_TRY(c, hipEventSynchronize(c->cev[1])); float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->cev[0], c->cev[1])); c->chunk_ms += ms; }
         HIP_TRY(c, hipGetLastError());
         c->chunk_steps += n; c->chunk_count++;
@@ -629,6 +638,8 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
     uint32_t remaining = n_steps, total = 0;
     int rc;
     bool sequential_only = !c->pipeline || c->phase_timing;
+    bool stalled = false, probing = false;
+    uint32_t backoff = 0, sync_chunks_left = 0;
     while (remaining > 0) {
         if (sequential_only) {
             uint32_t done = 0;
@@ -636,8 +647,38 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             total += done;
             break;
         }
+        if (c->time_parallel && !stalled && sync_chunks_left == 0) {
+            // Chunks are enqueued back to back without waiting for their k_decide: every kernel takes the chunk from the
+            // control block and is a no-op when the chunk cannot run time-parallel (then the steps simply do not advance,
+            // which the read-back below sees, and the synchronous path further down takes over for one chunk).
+            const uint32_t first = c->host_t, limit_t = first + remaining - 1u;
+            const uint32_t bursts = std::min<uint32_t>((remaining + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n, probing ? 1u : 64u);
+            const bool tk = c->kernel_timing;
+            if (tk) { if (!c->cev[0]) { (void)hipEventCreate(&c->cev[0]); (void)hipEventCreate(&c->cev[1]); } HIP_TRY(c, hipEventRecord(c->cev[0], c->stream)); }
+            for (uint32_t g = 0; g < bursts; ++g) {
+                hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+                hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1);
+                enqueue_parallel_chunk(c);
+            }
+            if (tk) HIP_TRY(c, hipEventRecord(c->cev[1], c->stream));
+            Ctrl h;
+            HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipGetLastError());
+            if (h.error) return fail(c, -(int)h.error, "device-side error");
+            const uint32_t done = h.t - first;
+            if (tk && done) { float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->cev[0], c->cev[1])); c->chunk_ms += ms; c->chunk_steps += done; c->chunk_count += (done + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n; }
+            c->host_t = h.t; total += done; remaining -= done;
+            if (h.finished) break;
+            if (done == 0) { backoff = std::min<uint32_t>(64u, backoff ? backoff * 2u : 1u); sync_chunks_left = backoff; probing = true; }
+            else { backoff = 0; probing = h.t <= limit_t; }
+            if (h.t <= limit_t) stalled = true;                  // something other than a full time-parallel chunk is next
+            continue;
+        }
+        stalled = false;
+        if (sync_chunks_left) --sync_chunks_left;
         const uint32_t n_ahead = std::min<uint32_t>(remaining, (uint32_t)c->xf_n);
-        hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, d, n_ahead);
+        hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, d, n_ahead, c->P.max_steps);
         uint32_t done = 0;
         Ctrl before;
         if ((rc = run_chunk(c, n_ahead, &done, &before))) return rc;
@@ -706,7 +747,7 @@ extern "C" int esim_future_infected(esim_ctx *ctx)
     esim_ctx_impl *c = CTX(ctx);
     if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "no population uploaded");
     HIP_TRY(c, hipSetDevice(c->P.device));
-    hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, c->d, (uint32_t)c->xf_n);
+    hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, c->d, (uint32_t)c->xf_n, c->P.max_steps);
     HIP_TRY(c, hipGetLastError());
     return ESIM_OK;
 }

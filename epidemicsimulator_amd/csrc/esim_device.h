@@ -65,14 +65,20 @@ struct Ctrl {
     uint32_t free_base;         // first step of the current free-running batch (decoupled sharded mode)
     uint32_t small_done;        // steps executed by the last k_small launch
     uint32_t chunk_ok;          // steps of the current chunk that may run pipelined (k_decide)
+    uint32_t chunk_t0;          // first step of the current chunk
+    uint32_t items_per_wave;    // item ids every wavefront of k_chunk_marks owns
     uint32_t chunk_parallel;    // 1: the chunk's marks fit the hash map, all its steps can be drawn in one pass
     uint32_t chunk_pairs;       // log entries that are Infected in some step of the chunk, this shard (k_future)
     uint32_t n_items;           // marked (building | room | route, step) entries of the chunk
     uint32_t n_newexp;          // citizens exposed in the chunk
     uint32_t n_units, unit_next; // deferred units of long member lists (k_chunk_units)
     uint32_t n_route_pairs;     // (route item, bus step) pairs with an Infected rider
-    uint32_t pad2[3];
+    uint32_t chunk_done;        // the books of the last time-parallel chunk were written (k_chunk_finish)
 };
+
+// An item of a time-parallel chunk: a building (a = residents, b = workers, aux = type), a school room (a =
+// participants, aux = its school building) or a route.
+struct ItemRec { uint32_t id, a_lo, a_hi, b_lo, b_hi, aux, pad0, pad1; };
 
 // What is in force during one step of a pipelined chunk (k_decide fills dec[0..chunk_ok]).
 struct Decision {
@@ -106,7 +112,8 @@ struct Dev {
     unsigned long long *hkey;   // [hcap] slot id (building | n_bld + room | n_bld + n_room + route), HKEY_EMPTY when free
     uint32_t *hval;             // [hcap] item index of the key
     uint32_t hcap;              // power of two
-    uint32_t *hitems;           // [items_cap] hash slot of each item of the chunk
+    uint32_t *hitems;           // [items_cap] hash slot of each item of the chunk (ITEM_UNUSED: id not handed out)
+    struct ItemRec *item_rec;   // [items_cap] what the draw pass needs of an item, written at claim time
     uint32_t *vec;              // [items_cap][FREE_MAX] infected standing in the item in each step of the chunk
     uint32_t items_cap;
     uint32_t *unit_item, *unit_lo;  // [units_cap] item | kind << 30, first pair of the unit

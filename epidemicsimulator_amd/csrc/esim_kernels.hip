@@ -478,12 +478,13 @@ __device__ __forceinline__ void block_scan_1024(uint32_t *v, uint32_t *wtmp)
     __syncthreads();
 }
 
-__global__ __launch_bounds__(FIN_TPB) void k_future(Dev d, uint32_t n_ahead)
+__global__ __launch_bounds__(FIN_TPB) void k_future(Dev d, uint32_t max_ahead, uint32_t limit_t)
 {
     __shared__ uint32_t win[BF_WIN];
     __shared__ uint32_t wtmp[FIN_TPB / 64];
     Ctrl *ctrl = d.ctrl;
     const uint32_t t0 = ctrl->t, tid = threadIdx.x;                        // t0: first step of the chunk
+    const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
     const int et = (int)d.exposed_time, it = (int)d.infected_time;
     const int base_idx = (int)(t0 + TE_BIAS) - et - 1 - it;               // lowest entry of the first Infected window
     { const int k = base_idx + (int)tid; win[tid] = (k >= 0 && k < (int)TE_SLOTS) ? d.hist[k] : 0u; }
@@ -510,7 +511,7 @@ __device__ __forceinline__ uint32_t mask_compose(uint32_t g, uint32_t f)
     return ((g >> (2u * (f & 3u))) & 3u) | (((g >> (2u * ((f >> 2) & 3u))) & 3u) << 2) | (((g >> (2u * ((f >> 4) & 3u))) & 3u) << 4);
 }
 
-__global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t n_ahead, int allow_parallel)
+__global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32_t limit_t, int allow_parallel)
 {
     // One wavefront, no serial loop.  Lane l evaluates the (strict) threshold tests of steps l and 64 + l
     // (interventions.rs:116-170).  Then, per step j of the chunk:
@@ -522,6 +523,7 @@ __global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t n_ahead, int allo
     Ctrl *ctrl = d.ctrl;
     const uint32_t lane = threadIdx.x;
     const uint32_t t0 = ctrl->t;
+    const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
     const uint32_t lim_in = n_ahead < FREE_MAX ? n_ahead : FREE_MAX;
     const bool ok = !ctrl->have_elig && !ctrl->vacc_active && !ctrl->finished && !ctrl->error && ctrl->free_base == t0;
     const uint32_t lock_init = ctrl->lockdown, mask_init = ctrl->mask, work_init = ctrl->at_work, bus_init = ctrl->bus_dir;
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t n_ahead, int allo
         if (lane == 0) d.dec[jn] = Decision{ lock_after, mask_after, aw_last, bd_last };
     }
     if (lane == 0) {
-        ctrl->chunk_ok = n_ok;
+        ctrl->chunk_ok = n_ok; ctrl->chunk_t0 = t0;
         // a citizen marks at most its home, its work building, its room and its route
         ctrl->chunk_parallel = (allow_parallel && d.items_cap && d.max_route <= CHUNK_ROUTE_MAX &&
                                 (unsigned long long)ctrl->chunk_pairs * 4ull + 65536ull <= (unsigned long long)d.items_cap) ? 1u : 0u;
@@ -676,13 +678,12 @@ __device__ __forceinline__ uint32_t hash64(unsigned long long k)
 
 // Items live in an open-addressing hash map keyed by slot id (building | n_bld + room | n_bld + n_room + route).
 // Claiming is two-phase so that a wavefront has published ALL its own claims before any of its lanes waits:
-// item_probe never waits; the claiming lanes then take indices from their wavefront's pool (ITEM_POOL indices per
-// global atomic -- one counter bumped once per claim would serialise the pass) and publish them; item_wait is
+// item_probe never waits; the claiming lanes then take indices from their wavefront's own id range (a counter
+// bumped once per claim would serialise the pass) and publish them; item_wait is
 // called after the lanes have reconverged by those that found the key already there, and waits (bounded) for the
 // index.  The claimer it waits for sits in a wavefront that is still probing or already past its claims -- never
 // itself waiting with an unpublished claim.
 #define HVAL_PENDING 0xFFFFFFFFu
-#define ITEM_POOL 8u
 #define ITEM_UNUSED 0xFFFFFFFFu
 __device__ __forceinline__ bool item_probe(const Dev &d, Ctrl *ctrl, unsigned long long key, uint32_t &slot, bool &pending)
 {
@@ -734,9 +735,11 @@ __device__ __forceinline__ uint32_t where_in_step(const Dev &d, uint32_t w, uint
 
 // generate_exposures (simulator.rs:181-198) for every step of the chunk: one wavefront per citizen that is
 // Infected somewhere in the chunk; lanes are the steps (two rounds of 64).
-__global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d, uint32_t t0, uint32_t n)
+__global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
 {
     Ctrl *ctrl = d.ctrl;
+    const uint32_t t0 = ctrl->chunk_t0, n = ctrl->chunk_ok;
+    if (!ctrl->chunk_parallel || n == 0u) return;
     {
         // the marks of step t0 - 1 (made by a sequential or pipelined step) would have been cleared by the exposure
         // pass of step t0; this chunk has none, so clear them here
@@ -750,13 +753,17 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d, uint32_t t0, uint32_
     }
     const int lo_te = (int)(t0 + TE_BIAS) - (int)d.exposed_time - 1 - (int)d.infected_time;     // Infected in step t0
     const int hi_te = (int)(t0 + n - 1u + TE_BIAS) - (int)d.exposed_time - 1;                    // Infected in step t0 + n - 1
-    if (hi_te < 0) return;
-    const uint32_t i0 = d.log_off[lo_te < 0 ? 0 : lo_te], i1 = d.log_off[hi_te + 1];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    const uint32_t i0 = hi_te < 0 ? 0u : d.log_off[lo_te < 0 ? 0 : lo_te], i1 = hi_te < 0 ? 0u : d.log_off[hi_te + 1];
+    // every wavefront owns a fixed range of item ids (a citizen claims at most four items), so no counter is shared
+    const uint32_t per_wave = 4u * ((i1 - i0 + n_waves - 1u) / n_waves);
+    if (wave == 0 && lane == 0) { ctrl->items_per_wave = per_wave; ctrl->n_items = per_wave * n_waves; }
+    if ((unsigned long long)per_wave * n_waves > d.items_cap) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); return; }
+    for (uint32_t i = lane; i < per_wave; i += 64u) d.hitems[wave * per_wave + i] = ITEM_UNUSED;
+    uint32_t next_id = wave * per_wave;
     const Decision q0 = lane < n ? d.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
     const Decision q1 = 64u + lane < n ? d.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
-    uint32_t pool_next = 0, pool_left = 0;
     for (uint32_t e = i0 + wave; e < i1; e += n_waves) {
         const uint32_t c = d.log[e];
         const uint32_t w = d.cit[c];
@@ -775,22 +782,18 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d, uint32_t t0, uint32_
         bool pending = false, claimed = false;
         if (key != HKEY_EMPTY) claimed = item_probe(d, ctrl, key, slot, pending);
         const unsigned long long cm = __ballot(claimed);
-        if (cm) {
-            const uint32_t need = (uint32_t)__popcll(cm);
-            if (pool_left < need) {                                           // wave-uniform
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&ctrl->n_items, ITEM_POOL);
-                pool_next = __shfl(base, 0, 64); pool_left = ITEM_POOL;
-                if (pool_next + ITEM_POOL > d.items_cap) { ctrl->error = (uint32_t)(-ESIM_ERANGE); pool_next = 0u; }
-                else if (lane < ITEM_POOL) d.hitems[pool_next + lane] = ITEM_UNUSED;
-            }
-            if (claimed) {
-                v = pool_next + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
-                d.hitems[v] = slot;
-                __hip_atomic_store(&d.hval[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // claims are published here ...
-            }
-            pool_next += need; pool_left -= need;
+        if (claimed) {
+            v = next_id + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
+            // what the draw pass needs of the item
+            const uint32_t id = (uint32_t)key;
+            ItemRec rec = { id, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+            if (id < d.n_bld) { rec.a_lo = d.res_off[id]; rec.a_hi = d.res_off[id + 1]; rec.b_lo = d.wrk_off[id]; rec.b_hi = d.wrk_off[id + 1]; rec.aux = d.bld_type[id]; }
+            else if (id < d.n_bld + d.n_room) { const uint32_t r = id - d.n_bld; rec.a_lo = d.room_off[r]; rec.a_hi = d.room_off[r + 1]; rec.aux = d.room_bld[r]; }
+            d.item_rec[v] = rec;
+            d.hitems[v] = slot;
+            __hip_atomic_store(&d.hval[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // claims are published here ...
         }
+        next_id += (uint32_t)__popcll(cm);
         __builtin_amdgcn_wave_barrier();
         if (pending) v = item_wait(d, ctrl, slot);                            // ... before any lane waits for somebody else's
         const uint32_t v_home = __shfl(v, 0, 64), v_work = __shfl(v, 1, 64), v_room = __shfl(v, 2, 64), v_bus = __shfl(v, 3, 64);
@@ -869,9 +872,9 @@ __device__ __forceinline__ uint32_t item_steps(const Dev &d, uint32_t v, uint32_
     return (uint32_t)(__popcll(b0) + __popcll(b1));
 }
 
-__device__ __forceinline__ void school_counts(const Dev &d, uint32_t room, uint32_t lane, uint32_t n, WaveScratch &ws)
+__device__ __forceinline__ void school_counts(const Dev &d, uint32_t school_bld, uint32_t lane, uint32_t n, WaveScratch &ws)
 {
-    const uint32_t v_sch = item_find(d, d.room_bld[room]);                    // infected in the whole school, per step
+    const uint32_t v_sch = item_find(d, school_bld);                          // infected in the whole school, per step
     ws.sch[lane] = (v_sch != 0xFFFFFFFFu && lane < n) ? d.vec[(size_t)v_sch * FREE_MAX + lane] : 0u;
     if (lane < FREE_MAX - 64u) ws.sch[64u + lane] = (v_sch != 0xFFFFFFFFu && 64u + lane < n) ? d.vec[(size_t)v_sch * FREE_MAX + 64u + lane] : 0u;
 }
@@ -897,11 +900,13 @@ __device__ __forceinline__ void list_or_units(const Dev &d, Ctrl *ctrl, const Ch
 }
 
 // apply_exposures (simulator.rs:262-405) for every item and every step of the chunk.
-__global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t t0, uint32_t n)
+__global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
 {
     __shared__ ChunkShared sm;
     __shared__ WaveScratch wsc[TPB / 64];
     Ctrl *ctrl = d.ctrl;
+    const uint32_t t0 = ctrl->chunk_t0, n = ctrl->chunk_ok;
+    if (!ctrl->chunk_parallel || n == 0u) return;
     for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
     for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
     __syncthreads();
@@ -912,24 +917,22 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t t0, uint32_t
     WaveScratch &ws = wsc[threadIdx.x >> 6];
     // (1) buildings and school rooms: one wavefront per item
     for (uint32_t v = wave; v < n_items; v += n_waves) {
-        const uint32_t hs = d.hitems[v];
-        if (hs == ITEM_UNUSED) continue;
-        const uint32_t id = (uint32_t)d.hkey[hs];
-        if (id >= route_base) continue;
-        if (id < d.n_bld) {
-            if (d.bld_type[id] == ESIM_SCHOOL) continue;                      // School::find_exposures works per room
+        if (d.hitems[v] == ITEM_UNUSED) continue;
+        const ItemRec rec = d.item_rec[v];
+        if (rec.id >= route_base) continue;
+        if (rec.id < d.n_bld) {
+            if (rec.aux == ESIM_SCHOOL) continue;                             // School::find_exposures works per room
             const uint32_t S = item_steps(d, v, lane, n, ws);
             __builtin_amdgcn_wave_barrier();
             // Household / Workplace::find_exposures: every registered occupant (building.rs:202-204,278-280)
-            list_or_units(d, ctrl, sm, ws, d.res_idx, d.res_off[id], d.res_off[id + 1], v, lane, 0u, S, t0);
-            list_or_units(d, ctrl, sm, ws, d.wrk_idx, d.wrk_off[id], d.wrk_off[id + 1], v, lane, 1u, S, t0);
+            list_or_units(d, ctrl, sm, ws, d.res_idx, rec.a_lo, rec.a_hi, v, lane, 0u, S, t0);
+            list_or_units(d, ctrl, sm, ws, d.wrk_idx, rec.b_lo, rec.b_hi, v, lane, 1u, S, t0);
         } else {
-            const uint32_t r = id - d.n_bld;
             const uint32_t S = item_steps(d, v, lane, n, ws);
-            school_counts(d, r, lane, n, ws);
+            school_counts(d, rec.aux, lane, n, ws);
             __builtin_amdgcn_wave_barrier();
             // School::find_exposures: the room once per infected in it (building.rs:494-522)
-            list_or_units(d, ctrl, sm, ws, d.room_idx, d.room_off[r], d.room_off[r + 1], v, lane, 2u, S, t0);
+            list_or_units(d, ctrl, sm, ws, d.room_idx, rec.a_lo, rec.a_hi, v, lane, 2u, S, t0);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -939,7 +942,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t t0, uint32_t
     const uint32_t n_pairs = min(ld(&ctrl->n_route_pairs), d.items_cap);
     for (uint32_t q = blockIdx.x; q < n_pairs; q += gridDim.x) {
         const uint32_t code = d.route_pairs[q], v = code >> 7, j = code & 127u;
-        const uint32_t r = (uint32_t)d.hkey[d.hitems[v]] - route_base;
+        const uint32_t r = d.item_rec[v].id - route_base;
         const uint32_t off = d.route_off[r], sz = d.route_off[r + 1] - off;
         const uint32_t s = t0 + j, mask = sm.dec[j].mask;
         for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
@@ -972,11 +975,13 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t t0, uint32_t
 }
 
 // The deferred units of long member lists, dealt to the wavefronts round-robin.
-__global__ __launch_bounds__(TPB) void k_chunk_units(Dev d, uint32_t t0, uint32_t n)
+__global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
 {
     __shared__ ChunkShared sm;
     __shared__ WaveScratch wsc[TPB / 64];
     Ctrl *ctrl = d.ctrl;
+    const uint32_t t0 = ctrl->chunk_t0, n = ctrl->chunk_ok;
+    if (!ctrl->chunk_parallel || n == 0u) return;
     const uint32_t n_units = min(ld(&ctrl->n_units), d.units_cap);
     if (n_units == 0) return;
     for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
@@ -987,13 +992,13 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d, uint32_t t0, uint32_
     WaveScratch &ws = wsc[threadIdx.x >> 6];
     for (uint32_t q = wave; q < n_units; q += n_waves) {
         const uint32_t code = d.unit_item[q], v = code & 0x3FFFFFFFu, kind = code >> 30, p_lo = d.unit_lo[q];
-        const uint32_t id = (uint32_t)d.hkey[d.hitems[v]];
+        const ItemRec rec = d.item_rec[v];
         const uint32_t S = item_steps(d, v, lane, n, ws);
         uint32_t lo, hi;
         const uint32_t *idx;
-        if (kind == 2u) { const uint32_t r = id - d.n_bld; lo = d.room_off[r]; hi = d.room_off[r + 1]; idx = d.room_idx; school_counts(d, r, lane, n, ws); }
-        else if (kind == 1u) { lo = d.wrk_off[id]; hi = d.wrk_off[id + 1]; idx = d.wrk_idx; }
-        else { lo = d.res_off[id]; hi = d.res_off[id + 1]; idx = d.res_idx; }
+        if (kind == 2u) { lo = rec.a_lo; hi = rec.a_hi; idx = d.room_idx; school_counts(d, rec.aux, lane, n, ws); }
+        else if (kind == 1u) { lo = rec.b_lo; hi = rec.b_hi; idx = d.wrk_idx; }
+        else { lo = rec.a_lo; hi = rec.a_hi; idx = d.res_idx; }
         __builtin_amdgcn_wave_barrier();
         const uint32_t pairs = (hi - lo) * S;
         member_pairs(d, ctrl, sm, ws, idx, lo, p_lo, min(pairs, p_lo + UNIT_PAIRS), lane, kind, S, t0);
@@ -1004,6 +1009,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d, uint32_t t0, uint32_
 // Exposures per step (statistics.rs:181) from the final citizen words.
 __global__ __launch_bounds__(TPB) void k_chunk_count(Dev d)
 {
+    if (!d.ctrl->chunk_parallel || d.ctrl->chunk_ok == 0u) return;
     const uint32_t n_new = ld(&d.ctrl->n_newexp);
     for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_new; i += gridDim.x * TPB) {
         const uint32_t w = d.cit[d.newexp[i]];
@@ -1014,9 +1020,11 @@ __global__ __launch_bounds__(TPB) void k_chunk_count(Dev d)
 
 // The chunk's exposures enter the log grouped by step (after k_batch_finish wrote the offsets); the hash map and
 // the count vectors are emptied for the next chunk.
-__global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d, uint32_t t0)
+__global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d)
 {
     Ctrl *ctrl = d.ctrl;
+    if (!ctrl->chunk_parallel || ctrl->chunk_done == 0u) return;
+    const uint32_t t0 = ctrl->chunk_t0;
     const uint32_t n_new = ld(&ctrl->n_newexp), n_items = min(ld(&ctrl->n_items), d.items_cap);
     for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_new; i += gridDim.x * TPB) {
         const uint32_t m = d.newexp[i];
@@ -1034,7 +1042,8 @@ __global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d, uint32_t t0)
 // The books of a pipelined chunk [t0, t0+n): census (simulator.rs:178) by sliding the Exposed / Infected
 // windows over the exposure histogram, the StatisticEntry of every step (statistics.rs:208-215, adjusted
 // by citizen_exposed :275-287), hist / log offsets, and the control block as it stands after the chunk.
-__global__ __launch_bounds__(FIN_TPB) void k_batch_finish(Dev d, uint32_t t0, uint32_t n)
+// (body shared by the two launch forms below)
+__device__ __forceinline__ void batch_finish_body(const Dev &d, uint32_t t0, uint32_t n)
 {
     __shared__ uint32_t P[BF_WIN + 1];                 // P[i + 1] = sum of H[0..i], P[0] = 0
     __shared__ uint32_t wtmp[FIN_TPB / 64];
@@ -1097,6 +1106,21 @@ __global__ __launch_bounds__(FIN_TPB) void k_batch_finish(Dev d, uint32_t t0, ui
         for (uint32_t z = 0; z < MARK_SLOTS; ++z)
             if (z != keep) { ctrl->n_touched_bld[z] = 0u; ctrl->n_touched_room[z] = 0u; ctrl->n_touched_route[z] = 0u; ctrl->n_touched_route_big[z] = 0u; }
     }
+}
+
+__global__ __launch_bounds__(FIN_TPB) void k_batch_finish(Dev d, uint32_t t0, uint32_t n)
+{
+    batch_finish_body(d, t0, n);
+}
+
+// Time-parallel chunks take (t0, n) from the control block, so that the host can enqueue chunk after chunk without
+// waiting for k_decide; chunk_done tells k_chunk_scatter (and the host) that the books of this chunk were written.
+__global__ __launch_bounds__(FIN_TPB) void k_chunk_finish(Dev d)
+{
+    Ctrl *ctrl = d.ctrl;
+    if (!ctrl->chunk_parallel || ctrl->chunk_ok == 0u) { if (threadIdx.x == 0) ctrl->chunk_done = 0u; return; }
+    batch_finish_body(d, ctrl->chunk_t0, ctrl->chunk_ok);
+    if (threadIdx.x == 0) ctrl->chunk_done = 1u;
 }
 
 // Vaccination bookkeeping for one citizen set to Vaccinated (simulator.rs:551).
