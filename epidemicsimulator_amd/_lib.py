@@ -86,7 +86,7 @@ SYMBOLS = [
     "esim_read_records", "esim_stream", "esim_set_stream",
     "esim_set_exchange_buffer", "esim_synchronize",
     "esim_download_state", "esim_enable_phase_timing", "esim_phase_timings",
-    "esim_enable_kernel_timing", "esim_kernel_timings", "esim_set_small_step_limit", "esim_small_kernel_timing",
+    "esim_enable_kernel_timing", "esim_kernel_timings", "esim_set_small_step_limit", "esim_small_kernel_timing", "esim_debug_counters",
     "esim_last_error", "esim_destroy",
     "esim_threshold_lut", "esim_synth_preset", "esim_synth_create", "esim_synth_create_shard", "esim_synth_free",
     "esim_shard_population",
@@ -132,6 +132,7 @@ def load():
         "esim_phase_timings": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "esim_enable_kernel_timing": (C.c_int, [vp, C.c_int]),
         "esim_kernel_timings": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+        "esim_debug_counters": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
         "esim_set_small_step_limit": (C.c_int, [vp, C.c_uint32]),
         "esim_small_kernel_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
         "esim_last_error": (C.c_char_p, [vp]),

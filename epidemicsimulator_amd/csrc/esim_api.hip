@@ -331,6 +331,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if ((rc = dev_alloc(c, &d.unit_item, d.units_cap))) return rc;
         if ((rc = dev_alloc(c, &d.unit_lo, d.units_cap))) return rc;
         if ((rc = dev_alloc(c, &d.route_pairs, d.items_cap))) return rc;
+        if ((rc = dev_alloc(c, &d.route_pairs_big, d.items_cap))) return rc;
         HIP_TRY(c, hipMemset(d.hval, 0xFF, sizeof(uint32_t) * cap));
         if ((rc = dev_alloc(c, &d.newexp, (size_t)N + 1))) return rc;
         if ((rc = dev_alloc(c, &d.cursor, FREE_MAX))) return rc;
@@ -800,6 +801,20 @@ extern "C" int esim_pipeline_timing(esim_ctx *ctx, double *mean_step_ms, uint64_
     if (steps_timed) *steps_timed = n;
     if (steps_run) *steps_run = c->pipe_steps;
     c->pkev_used = 0; c->pipe_steps = 0;
+    return ESIM_OK;
+}
+
+extern "C" int esim_debug_counters(esim_ctx *ctx, uint32_t out[16])
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded || !out) return ESIM_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    Ctrl h;
+    HIP_TRY(c, hipMemcpy(&h, c->d.ctrl, sizeof h, hipMemcpyDeviceToHost));
+    const uint32_t v[16] = { h.t, h.chunk_ok, h.chunk_parallel, h.chunk_pairs, h.n_items, h.items_per_wave, h.n_units, h.n_route_pairs,
+                             h.n_route_pairs_big, h.n_newexp, h.log_len, h.n_susceptible, h.lockdown, h.mask, h.at_work, h.bus_dir };
+    std::memcpy(out, v, sizeof v);
     return ESIM_OK;
 }
 

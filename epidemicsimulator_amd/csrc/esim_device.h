@@ -72,7 +72,8 @@ struct Ctrl {
     uint32_t n_items;           // marked (building | room | route, step) entries of the chunk
     uint32_t n_newexp;          // citizens exposed in the chunk
     uint32_t n_units, unit_next; // deferred units of long member lists (k_chunk_units)
-    uint32_t n_route_pairs;     // (route item, bus step) pairs with an Infected rider
+    uint32_t n_route_pairs;     // (route item, bus step) pairs with an Infected rider, routes of <= 64 riders
+    uint32_t n_route_pairs_big; // ... routes of more riders
     uint32_t chunk_done;        // the books of the last time-parallel chunk were written (k_chunk_finish)
 };
 
@@ -117,7 +118,8 @@ struct Dev {
     uint32_t *vec;              // [items_cap][FREE_MAX] infected standing in the item in each step of the chunk
     uint32_t items_cap;
     uint32_t *unit_item, *unit_lo;  // [units_cap] item | kind << 30, first pair of the unit
-    uint32_t *route_pairs;      // [items_cap] route item << 7 | step of the chunk
+    uint32_t *route_pairs;      // [items_cap] route item << 7 | step of the chunk (routes of <= 64 riders)
+    uint32_t *route_pairs_big;  // [items_cap]
     uint32_t units_cap;
     uint32_t *newexp;           // [n] citizens exposed in the chunk
     uint32_t *cursor;           // [FREE_MAX] per-step write cursors into the log

@@ -627,7 +627,7 @@ __global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32
         // a citizen marks at most its home, its work building, its room and its route
         ctrl->chunk_parallel = (allow_parallel && d.items_cap && d.max_route <= CHUNK_ROUTE_MAX &&
                                 (unsigned long long)ctrl->chunk_pairs * 4ull + 65536ull <= (unsigned long long)d.items_cap) ? 1u : 0u;
-        ctrl->n_items = 0u; ctrl->n_newexp = 0u; ctrl->n_units = 0u; ctrl->unit_next = 0u; ctrl->n_route_pairs = 0u;
+        ctrl->n_items = 0u; ctrl->n_newexp = 0u; ctrl->n_units = 0u; ctrl->unit_next = 0u; ctrl->n_route_pairs = 0u; ctrl->n_route_pairs_big = 0u;
     }
     d.cursor[lane] = 0u;
     if (lane < FREE_MAX - 64u) d.cursor[64u + lane] = 0u;
@@ -784,14 +784,14 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         const unsigned long long cm = __ballot(claimed);
         if (claimed) {
             v = next_id + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
-            // what the draw pass needs of the item
+            d.hitems[v] = slot;
+            __hip_atomic_store(&d.hval[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // claims are published here ...
+            // what the draw pass needs of the item (read by later kernels only)
             const uint32_t id = (uint32_t)key;
             ItemRec rec = { id, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
             if (id < d.n_bld) { rec.a_lo = d.res_off[id]; rec.a_hi = d.res_off[id + 1]; rec.b_lo = d.wrk_off[id]; rec.b_hi = d.wrk_off[id + 1]; rec.aux = d.bld_type[id]; }
             else if (id < d.n_bld + d.n_room) { const uint32_t r = id - d.n_bld; rec.a_lo = d.room_off[r]; rec.a_hi = d.room_off[r + 1]; rec.aux = d.room_bld[r]; }
             d.item_rec[v] = rec;
-            d.hitems[v] = slot;
-            __hip_atomic_store(&d.hval[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // claims are published here ...
         }
         next_id += (uint32_t)__popcll(cm);
         __builtin_amdgcn_wave_barrier();
@@ -802,8 +802,14 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         if (p0 & 2u) { atomicAdd(&d.vec[(size_t)v_work * FREE_MAX + lane], 1u); if (school) atomicAdd(&d.vec[(size_t)v_room * FREE_MAX + lane], 1u); }
         if (p1 & 2u) { atomicAdd(&d.vec[(size_t)v_work * FREE_MAX + 64u + lane], 1u); if (school) atomicAdd(&d.vec[(size_t)v_room * FREE_MAX + 64u + lane], 1u); }
         // the first Infected rider of a (route, step) registers the pair: each gets a workgroup of its own in k_chunk_draw
-        if ((p0 & 4u) && atomicAdd(&d.vec[(size_t)v_bus * FREE_MAX + lane], 1u) == 0u) append(d.route_pairs, &ctrl->n_route_pairs, (v_bus << 7) | lane);
-        if ((p1 & 4u) && atomicAdd(&d.vec[(size_t)v_bus * FREE_MAX + 64u + lane], 1u) == 0u) append(d.route_pairs, &ctrl->n_route_pairs, (v_bus << 7) | (64u + lane));
+        if (any_bus) {
+            const uint32_t rt = d.route_of[c];
+            const bool small = d.route_off[rt + 1] - d.route_off[rt] <= 64u;
+            uint32_t *list = small ? d.route_pairs : d.route_pairs_big;
+            uint32_t *len = small ? &ctrl->n_route_pairs : &ctrl->n_route_pairs_big;
+            if ((p0 & 4u) && atomicAdd(&d.vec[(size_t)v_bus * FREE_MAX + lane], 1u) == 0u) append(list, len, (v_bus << 7) | lane);
+            if ((p1 & 4u) && atomicAdd(&d.vec[(size_t)v_bus * FREE_MAX + 64u + lane], 1u) == 0u) append(list, len, (v_bus << 7) | (64u + lane));
+        }
     }
 }
 
@@ -823,38 +829,49 @@ struct ChunkShared {
     uint8_t s_inf[CHUNK_ROUTE_MAX];
     uint32_t s_cnt[CHUNK_ROUTE_MAX + 1];
 };
-struct WaveScratch { uint32_t cnt[FREE_MAX]; uint32_t sch[FREE_MAX]; uint8_t steps[FREE_MAX]; };
+struct WaveScratch { uint32_t cnt[FREE_MAX]; uint32_t sch[FREE_MAX]; uint32_t mem_id[64]; uint32_t mem_w[64]; uint8_t steps[FREE_MAX]; };
 
 // One member list of one item over the marked steps of the chunk: the (member, marked step) pairs [p_lo, p_hi) are
 // spread densely over the 64 lanes (the draws are Philox-bound -- 20 quarter-rate multiplies each -- so idle lanes
 // are what costs).  ws.steps: the item's marked steps in order, S of them; ws.cnt / ws.sch: the item's / the school's
 // Infected per step.  kind 0 residents, 1 workers, 2 room participants.
-__device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, const WaveScratch &ws, const uint32_t *idx,
+__device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, WaveScratch &ws, const uint32_t *idx,
                                              uint32_t lo, uint32_t p_lo, uint32_t p_hi, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0)
 {
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
-    for (uint32_t p = p_lo + lane; p < p_hi; p += 64u) {
-        const uint32_t um = p / S, j = ws.steps[p - um * S];
-        const uint32_t m = idx ? idx[lo + um] : lo + um;
-        const uint32_t w = d.cit[m];
-        const uint32_t te = CW_TE(w), s = t0 + j;
-        if (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) continue;
-        // Susceptible when this list is walked in step s: never exposed, or so far only exposed by something that
-        // comes later (a later step, or a bus of this step) -- that exposure may be undercut
-        if (w <= CW_MAKE(s + TE_BIAS, w & CW_FLAGS)) continue;
-        const uint32_t at_work = sm.dec[j].at_work, mask = sm.dec[j].mask;
-        const bool same = w & FL_SAME_AREA;
-        if (kind == 0u) { if (at_work && (w & FL_HAS_WORK) && !same) continue; }           // simulator.rs:324
-        else if (!at_work && !same) continue;
-        const uint32_t cnt = ws.cnt[j];
-        const uint32_t nn = kind == 2u ? ws.sch[j] : cnt;                                   // exposure_count: infected in the building
-        const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
-        const uint64_t thr = sm.thr[row * 256u + (nn & 255u)];
-        const uint32_t gid = d.id_base + m;
-        bool hit = false;
-        if (kind == 2u) { for (uint32_t k = 0; k < cnt && !hit; ++k) hit = esim_u53(seed, gid, s, ESIM_SLOT_ROOM0 + k) < thr; }
-        else hit = esim_u53(seed, gid, s, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK) < thr;
-        if (hit) expose_min(d, ctrl, m, w, s, 0u);
+    // members touched by the pairs [p_lo, p_hi): staged in LDS 64 at a time -- every member recurs once per marked step
+    const uint32_t m_first = p_lo / S, m_last = (p_hi - 1u) / S;
+    for (uint32_t mb = m_first; mb <= m_last; mb += 64u) {
+        __builtin_amdgcn_wave_barrier();
+        if (mb + lane <= m_last) {
+            const uint32_t m = idx ? idx[lo + mb + lane] : lo + mb + lane;
+            ws.mem_id[lane] = m;
+            ws.mem_w[lane] = d.cit[m];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t q_lo = max(p_lo, mb * S), q_hi = min(p_hi, (mb + 64u) * S);
+        for (uint32_t p = q_lo + lane; p < q_hi; p += 64u) {
+            const uint32_t um = p / S, j = ws.steps[p - um * S];
+            const uint32_t m = ws.mem_id[um - mb], w = ws.mem_w[um - mb];
+            const uint32_t te = CW_TE(w), s = t0 + j;
+            if (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) continue;
+            // Susceptible when this list is walked in step s: never exposed, or so far only exposed by something that
+            // comes later (a later step, or a bus of this step) -- that exposure may be undercut
+            if (w <= CW_MAKE(s + TE_BIAS, w & CW_FLAGS)) continue;
+            const uint32_t at_work = sm.dec[j].at_work, mask = sm.dec[j].mask;
+            const bool same = w & FL_SAME_AREA;
+            if (kind == 0u) { if (at_work && (w & FL_HAS_WORK) && !same) continue; }       // simulator.rs:324
+            else if (!at_work && !same) continue;
+            const uint32_t cnt = ws.cnt[j];
+            const uint32_t nn = kind == 2u ? ws.sch[j] : cnt;                               // exposure_count: infected in the building
+            const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
+            const uint64_t thr = sm.thr[row * 256u + (nn & 255u)];
+            const uint32_t gid = d.id_base + m;
+            bool hit = false;
+            if (kind == 2u) { for (uint32_t k = 0; k < cnt && !hit; ++k) hit = esim_u53(seed, gid, s, ESIM_SLOT_ROOM0 + k) < thr; }
+            else hit = esim_u53(seed, gid, s, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK) < thr;
+            if (hit) expose_min(d, ctrl, m, w, s, 0u);
+        }
     }
 }
 
@@ -882,7 +899,7 @@ __device__ __forceinline__ void school_counts(const Dev &d, uint32_t school_bld,
 // Lists with more pairs than this are cut into units that any wavefront can take (k_chunk_units), so that one
 // 200-member workplace does not keep a single wavefront busy while the chip idles.
 #define UNIT_PAIRS 1024u
-__device__ __forceinline__ void list_or_units(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, const WaveScratch &ws, const uint32_t *idx,
+__device__ __forceinline__ void list_or_units(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, WaveScratch &ws, const uint32_t *idx,
                                               uint32_t lo, uint32_t hi, uint32_t v, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0)
 {
     const uint32_t pairs = (hi - lo) * S;
@@ -936,12 +953,47 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
         }
         __builtin_amdgcn_wave_barrier();
     }
-    // (2) routes: one workgroup per (route, bus step) with an Infected rider; rank by (Philox key, id) through LDS,
-    // buses are runs of bus_capacity ranks (simulator.rs:362-388)
+    // (2) routes of <= 64 riders: one wavefront per (route, bus step) with an Infected rider; rank by (Philox key, id)
+    // with shuffles, buses are runs of bus_capacity ranks (simulator.rs:362-388)
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
-    const uint32_t n_pairs = min(ld(&ctrl->n_route_pairs), d.items_cap);
-    for (uint32_t q = blockIdx.x; q < n_pairs; q += gridDim.x) {
+    const uint32_t n_small = min(ld(&ctrl->n_route_pairs), d.items_cap);
+    for (uint32_t q = wave; q < n_small; q += n_waves) {
         const uint32_t code = d.route_pairs[q], v = code >> 7, j = code & 127u;
+        const uint32_t r = d.item_rec[v].id - route_base;
+        const uint32_t off = d.route_off[r], sz = d.route_off[r + 1] - off;
+        const uint32_t s = t0 + j, mask = sm.dec[j].mask;
+        uint32_t c = 0, w = 0, key = 0;
+        bool inf = false;
+        if (lane < sz) {
+            c = d.route_riders[off + lane];
+            w = d.cit[c];
+            inf = status_of(CW_TE(w), s, d.exposed_time, d.infected_time) == ESIM_INFECTED;
+            key = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
+        }
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < sz; ++i) {
+            const uint32_t ki = __shfl(key, (int)i, 64);
+            rank += ki < key || (ki == key && i < lane);                     // ids ascend with the lane
+        }
+        const uint32_t bus = rank / d.bus_capacity;
+        uint32_t k = 0;
+        for (uint32_t i = 0; i < sz; ++i) {
+            const uint32_t bi = __shfl(bus, (int)i, 64);
+            const bool ii = __shfl((int)inf, (int)i, 64);
+            k += ii && bi == bus;
+        }
+        if (lane < sz && k) {
+            const uint32_t te = CW_TE(w);
+            if (!(w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_FLAGS)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE))) {   // not exposed before this bus
+                const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
+                if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
+            }
+        }
+    }
+    // (3) longer routes: one workgroup per (route, bus step), ranks through LDS
+    const uint32_t n_pairs = min(ld(&ctrl->n_route_pairs_big), d.items_cap);
+    for (uint32_t q = blockIdx.x; q < n_pairs; q += gridDim.x) {
+        const uint32_t code = d.route_pairs_big[q], v = code >> 7, j = code & 127u;
         const uint32_t r = d.item_rec[v].id - route_base;
         const uint32_t off = d.route_off[r], sz = d.route_off[r + 1] - off;
         const uint32_t s = t0 + j, mask = sm.dec[j].mask;

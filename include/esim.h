@@ -212,6 +212,11 @@ int  esim_small_kernel_timing(esim_ctx *ctx, double *total_ms, uint64_t *steps);
  * pipelined since the last call. */
 int  esim_pipeline_timing(esim_ctx *ctx, double *mean_step_ms, uint64_t *steps_timed, uint64_t *steps_run);
 
+/* Diagnostics: the control block's view of the last chunk (t, chunk_ok, chunk_parallel, chunk_pairs, n_items,
+ * items_per_wave, n_units, n_route_pairs, n_route_pairs_big, n_newexp, log_len, n_susceptible, lockdown, mask,
+ * at_work, bus_dir). */
+int  esim_debug_counters(esim_ctx *ctx, uint32_t out[16]);
+
 const char *esim_last_error(const esim_ctx *ctx);   /* ctx may be NULL: last esim_create error */
 void esim_destroy(esim_ctx *ctx);
 
