@@ -29,6 +29,7 @@ struct esim_ctx_impl {
     uint32_t *cnt_base = nullptr;
     uint32_t n_routes = 0;
     size_t xa_n = 0, xb_n = 0, xf_n = 0;
+    uint32_t free_limit = 0, free_first = 0;     // open burst of decoupled chunks: last step it may reach, first step
     uint32_t host_t = 1;          // next time step to enqueue
     // device allocations
     std::vector<void *> allocs;
@@ -45,6 +46,7 @@ struct esim_ctx_impl {
     hipEvent_t cev[2] = { nullptr, nullptr }; double chunk_ms = 0; uint64_t chunk_steps = 0, chunk_count = 0;
     uint32_t grid_chunk = 1024;
     bool pipeline = true;              // run chunks of steps as one kernel per step while no vaccination programme runs
+    std::vector<hipEvent_t> fev; size_t fev_used = 0;                               // chunks of an open decoupled burst
     std::vector<hipEvent_t> pkev; size_t pkev_used = 0; uint64_t pipe_steps = 0;   // sampled k_pipe launches
     uint32_t small_max = 128;          // infected-slice length up to which the persistent single-workgroup kernel runs a step
     hipEvent_t sev[2] = { nullptr, nullptr };   // k_small timing
@@ -182,6 +184,7 @@ extern "C" void esim_destroy(esim_ctx *ctx)
     for (auto &ev : c->kev) (void)hipEventDestroy(ev);
     for (auto &ev : c->sev) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->pkev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->fev) (void)hipEventDestroy(ev);
     for (auto &ev : c->cev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -327,7 +330,17 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if ((rc = dev_alloc(c, &d.hitems, d.items_cap))) return rc;
         if ((rc = dev_alloc(c, &d.item_rec, d.items_cap))) return rc;
         if ((rc = dev_alloc(c, &d.vec, (size_t)d.items_cap * FREE_MAX))) return rc;
-        d.units_cap = (uint32_t)std::min<size_t>((size_t)N / 8u + 1024u, 1u << 26);
+        // deferred units: the most a chunk can ask for is every long member list marked in every step
+        size_t units = 1024;
+        auto add_lists = [&](const std::vector<uint32_t> &off) {
+            for (size_t i = 0; i + 1 < off.size(); ++i) {
+                const size_t pairs = (size_t)(off[i + 1] - off[i]) * FREE_MAX;
+                if (pairs > UNIT_PAIRS) units += (pairs + UNIT_PAIRS - 1) / UNIT_PAIRS;
+            }
+        };
+        add_lists(res_off); add_lists(wrk_off); add_lists(room_off);
+        if (units > 0xFFFFFFF0ull) return fail(c, ESIM_ERANGE, "population too large for the unit table");
+        d.units_cap = (uint32_t)units;
         if ((rc = dev_alloc(c, &d.unit_item, d.units_cap))) return rc;
         if ((rc = dev_alloc(c, &d.unit_lo, d.units_cap))) return rc;
         if ((rc = dev_alloc(c, &d.route_pairs, d.items_cap))) return rc;
@@ -379,8 +392,9 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     if ((rc = dev_alloc(c, &d.xa, c->xa_n))) return rc;
     if ((rc = dev_alloc(c, &d.xb, c->xb_n))) return rc;
     c->xf_n = std::min<uint32_t>(FREE_MAX, c->P.exposed_time + 1u);
-    if ((rc = dev_alloc(c, &d.xf, FREE_MAX))) return rc;
-    HIP_TRY(c, hipMemset(d.xf, 0, sizeof(uint32_t) * FREE_MAX));
+    d.xf_n = (uint32_t)c->xf_n;
+    if ((rc = dev_alloc(c, &d.xf, FREE_MAX + 1))) return rc;
+    HIP_TRY(c, hipMemset(d.xf, 0, sizeof(uint32_t) * (FREE_MAX + 1)));
     HIP_TRY(c, hipMemset(d.xa, 0, sizeof(uint32_t) * c->xa_n));
     HIP_TRY(c, hipMemset(d.xb, 0, sizeof(uint32_t) * c->xb_n));
 
@@ -422,6 +436,7 @@ extern "C" int esim_reset(esim_ctx *ctx)
     HIP_TRY(c, hipMemcpy(d.log_off, off.data(), sizeof(uint32_t) * (TE_SLOTS + 1), hipMemcpyHostToDevice));
     if (n_seeds) HIP_TRY(c, hipMemcpy(d.log, c->init_log.data(), sizeof(uint32_t) * n_seeds, hipMemcpyHostToDevice));
     c->host_t = 1;
+    c->free_limit = 0;
     c->phase_s[0] = c->phase_s[1] = c->phase_s[2] = 0;
     c->kev_used = 0;
     c->small_ms = 0; c->small_steps = 0;
@@ -748,8 +763,60 @@ extern "C" int esim_future_infected(esim_ctx *ctx)
     esim_ctx_impl *c = CTX(ctx);
     if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "no population uploaded");
     HIP_TRY(c, hipSetDevice(c->P.device));
-    hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, c->d, (uint32_t)c->xf_n, c->P.max_steps);
+    hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, c->d, (uint32_t)c->xf_n, c->free_limit ? c->free_limit : c->P.max_steps);
     HIP_TRY(c, hipGetLastError());
+    return ESIM_OK;
+}
+
+// A burst of decoupled chunks without a host round trip per chunk: the caller repeats
+// { esim_future_infected; all-reduce F; esim_free_enqueue } and then collects once.
+extern "C" int esim_free_begin(esim_ctx *ctx, uint32_t n_steps)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    int rc = check_budget(c, n_steps);
+    if (rc) return rc;
+    if (n_steps == 0) return fail(c, ESIM_EINVAL, "esim_free_begin: no steps");
+    if (c->d.n_shared_bld || c->d.n_shared_room) return fail(c, ESIM_ESTATE, "esim_free_begin: shards that share buildings need the coupled steps");
+    if (!c->pipeline || !c->time_parallel) return fail(c, ESIM_ESTATE, "esim_free_begin: needs pipeline level 2");
+    c->free_limit = c->host_t + n_steps - 1u;
+    c->free_first = c->host_t;
+    return ESIM_OK;
+}
+
+extern "C" int esim_free_enqueue(esim_ctx *ctx)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded || !c->free_limit) return fail(c, ESIM_ESTATE, "esim_free_enqueue: no burst open (esim_free_begin)");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    bool tk = c->kernel_timing;
+    if (tk && c->fev_used + 2 > c->fev.size())
+        for (int i = 0; i < 2 && tk; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) tk = false; else c->fev.push_back(e); }
+    if (tk) HIP_TRY(c, hipEventRecord(c->fev[c->fev_used], c->stream));
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d, (uint32_t)c->xf_n, c->free_limit, 1);
+    enqueue_parallel_chunk(c);
+    if (tk) { HIP_TRY(c, hipEventRecord(c->fev[c->fev_used + 1], c->stream)); c->fev_used += 2; }
+    HIP_TRY(c, hipGetLastError());
+    return ESIM_OK;
+}
+
+extern "C" int esim_free_collect(esim_ctx *ctx, uint32_t *n_done)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded || !c->free_limit) return fail(c, ESIM_ESTATE, "esim_free_collect: no burst open (esim_free_begin)");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    c->free_limit = 0;
+    Ctrl h;
+    HIP_TRY(c, hipMemcpyAsync(&h, c->d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (h.error) return fail(c, -(int)h.error, "device-side error");
+    const uint32_t done = h.t - c->free_first;
+    // device time of the chunks of the burst (k_future and the collective in front of each are not inside the pairs)
+    for (size_t i = 0; i + 1 < c->fev_used; i += 2) { float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->fev[i], c->fev[i + 1])); if (done) c->chunk_ms += ms; }
+    c->fev_used = 0;
+    c->chunk_steps += done;
+    c->chunk_count += (done + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n;
+    c->host_t = h.t;
+    if (n_done) *n_done = done;
     return ESIM_OK;
 }
 
@@ -832,7 +899,7 @@ extern "C" int esim_exchange_buffer(esim_ctx *ctx, int which, void **device_ptr,
     if (!c || !c->uploaded) return fail(c, ESIM_ESTATE, "no population uploaded");
     if (which < 0 || which > 2) return fail(c, ESIM_EINVAL, "esim_exchange_buffer: which must be 0, 1 or 2");
     if (device_ptr) *device_ptr = which == 2 ? (void *)c->d.xf : which ? (void *)c->d.xb : (void *)c->d.xa;
-    if (n_u32) *n_u32 = which == 2 ? c->xf_n : which ? c->xb_n : c->xa_n;
+    if (n_u32) *n_u32 = which == 2 ? c->xf_n + 1 : which ? c->xb_n : c->xa_n;
     return ESIM_OK;
 }
 

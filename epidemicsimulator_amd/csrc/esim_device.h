@@ -146,6 +146,8 @@ struct Dev {
     uint32_t n_shared_bld, n_shared_room;
     const int32_t *shared_bld, *shared_room;
     uint32_t *xa, *xb, *xf;             // exchange buffers A, B and the future-infected vector
+    uint32_t xf_n;                      // steps buffer F covers (min(FREE_MAX, exposed_time + 1)); word xf[xf_n]: shards whose
+                                        // chunk does not fit the one-pass form
 };
 
 // exchange buffer A: [0..4] census, [5] riders, then shared building counts, then shared room counts
@@ -153,7 +155,9 @@ struct Dev {
 // exchange buffer B: [0] building exposures, [1] bus exposures, [2] eligible count, [3] error, then
 // VACC_BATCH/32 words of candidate liveness bits
 #define XB_HEADER 8u
-// exchange buffer F: Infected census of the next FREE_MAX steps (decoupled sharded mode)
+// exchange buffer F: Infected census of the next xf_n <= FREE_MAX steps, then one word counting the shards that cannot
+// draw the chunk in one pass
 #define FREE_MAX 96u
 #define HKEY_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define UNIT_PAIRS 1024u           // (member, marked step) pairs per deferred unit of a long member list
 #define CHUNK_ROUTE_MAX 2048u      // routes up to this many riders are ranked in LDS by the time-parallel pass

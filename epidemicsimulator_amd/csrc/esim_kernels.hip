@@ -498,7 +498,14 @@ __global__ __launch_bounds__(FIN_TPB) void k_future(Dev d, uint32_t max_ahead, u
     if (tid == 0) {
         ctrl->free_base = t0;
         // citizens Infected in at least one step of the chunk: exposure steps [first window's low end, last window's top]
-        ctrl->chunk_pairs = n_ahead ? win[n_ahead - 1u + (uint32_t)it] : 0u;
+        const uint32_t pairs = n_ahead ? win[n_ahead - 1u + (uint32_t)it] : 0u;
+        ctrl->chunk_pairs = pairs;
+        // Can this shard draw the chunk in one pass?  A citizen marks at most its home, its work building, its room and
+        // its route.  The word after the census counts the shards that cannot, so that after the all-reduce every shard
+        // takes the same form of the chunk (speculatively enqueued chunks advance on all shards or on none).
+        const bool fits = d.items_cap && d.max_route <= CHUNK_ROUTE_MAX &&
+                          (unsigned long long)pairs * 4ull + 65536ull <= (unsigned long long)d.items_cap;
+        d.xf[d.xf_n] = fits ? 0u : 1u;
     }
 }
 
@@ -624,9 +631,7 @@ __global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32
     }
     if (lane == 0) {
         ctrl->chunk_ok = n_ok; ctrl->chunk_t0 = t0;
-        // a citizen marks at most its home, its work building, its room and its route
-        ctrl->chunk_parallel = (allow_parallel && d.items_cap && d.max_route <= CHUNK_ROUTE_MAX &&
-                                (unsigned long long)ctrl->chunk_pairs * 4ull + 65536ull <= (unsigned long long)d.items_cap) ? 1u : 0u;
+        ctrl->chunk_parallel = (allow_parallel && d.xf[d.xf_n] == 0u) ? 1u : 0u;
         ctrl->n_items = 0u; ctrl->n_newexp = 0u; ctrl->n_units = 0u; ctrl->unit_next = 0u; ctrl->n_route_pairs = 0u; ctrl->n_route_pairs_big = 0u;
     }
     d.cursor[lane] = 0u;
@@ -898,7 +903,6 @@ __device__ __forceinline__ void school_counts(const Dev &d, uint32_t school_bld,
 
 // Lists with more pairs than this are cut into units that any wavefront can take (k_chunk_units), so that one
 // 200-member workplace does not keep a single wavefront busy while the chip idles.
-#define UNIT_PAIRS 1024u
 __device__ __forceinline__ void list_or_units(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, WaveScratch &ws, const uint32_t *idx,
                                               uint32_t lo, uint32_t hi, uint32_t v, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0)
 {

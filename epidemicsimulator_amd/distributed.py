@@ -101,7 +101,9 @@ class ShardedSimulator:
                 t = torch.zeros(max(1, n.value), dtype=torch.int32, device="cuda:%d" % device_index)
                 _lib.check(self.lib.esim_set_exchange_buffer(self._ctx, which, C.c_void_p(t.data_ptr())), self._ctx)
                 self.xbuf.append(t)
-            self.free_batch = int(self.xbuf[2].numel())
+            self.free_batch = int(self.xbuf[2].numel()) - 1     # the last word counts shards that need the per-step form
+            self.burst_max = 32                                 # chunks kept in flight between two host waits
+            self._burst, self._backoff, self._sync_left = 1, 0, 0
             torch.cuda.synchronize()
 
     # ------------------------------------------------------------------------------------------
@@ -118,7 +120,36 @@ class ShardedSimulator:
         done = 0
         with torch.cuda.stream(self.stream):
             while done < n_steps:
+                if self.mode_free and self.burst_max > 0 and self._sync_left == 0:
+                    # several whole chunks in flight: { census ahead; all-reduce; chunk } x burst, one wait at the end.
+                    # A chunk that cannot run this way is a no-op on every rank; the chunk-by-chunk form below then
+                    # takes it and the burst length starts again from one.
+                    want = n_steps - done
+                    chunks = min(-(-want // self.free_batch), self._burst)
+                    _lib.check(lib.esim_free_begin(ctx, want), ctx)
+                    for _ in range(chunks):
+                        _lib.check(lib.esim_future_infected(ctx), ctx)
+                        dist.all_reduce(self.xbuf[2], group=self.group)
+                        _lib.check(lib.esim_free_enqueue(ctx), ctx)
+                    got = C.c_uint32(0)
+                    _lib.check(lib.esim_free_collect(ctx, C.byref(got)), ctx)
+                    n_free = got.value
+                    if n_free > 0:
+                        self._local_ranges.append((self._steps + 1, self._steps + n_free))
+                        self._steps += n_free
+                        self.free_steps += n_free
+                        done += n_free
+                    if n_free >= min(want, chunks * self.free_batch):
+                        self._burst = min(self.burst_max, self._burst * 2)
+                        self._backoff = 0
+                    else:
+                        # the next chunk goes one at a time; chunks that keep failing are probed less and less often
+                        self._backoff = 0 if n_free else min(64, max(1, 2 * self._backoff))
+                        self._sync_left = max(1, self._backoff)
+                        self._burst = 1
+                    continue
                 if self.mode_free:
+                    self._sync_left = max(0, self._sync_left - 1)
                     _lib.check(lib.esim_future_infected(ctx), ctx)
                     dist.all_reduce(self.xbuf[2], group=self.group)
                     want = min(self.free_batch, n_steps - done)
@@ -177,6 +208,7 @@ class ShardedSimulator:
         self._steps = 0
         self._local_ranges = []
         self.coupled_steps = self.free_steps = 0
+        self._burst, self._backoff, self._sync_left = 1, 0, 0
         if self.sharded:
             free = bool(decoupled) and self.population.n_shared_buildings == 0 and self.population.n_shared_rooms == 0
             flag = self.torch.tensor([0 if free else 1], dtype=self.torch.int32, device="cuda:%d" % self.params.device)

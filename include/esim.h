@@ -155,6 +155,13 @@ int  esim_exchange_buffer(esim_ctx *ctx, int which /* 0 = A, 1 = B, 2 = F */, vo
  *   esim_run_free(k, &done) -- runs min(k, steps before the one that would start vaccinating) whole steps
  *                              with no exchange; records hold THIS shard's census; done < k means the next
  *                              step must be a coupled one (esim_step_begin / _exposures / _finish).
+ * Buffer F holds n + 1 words: the census of the next n steps and one word counting the shards whose chunk does
+ * not fit the one-pass form below (after the all-reduce every shard therefore takes the same form).
+ * Bursts: esim_run_free waits for the device once per chunk.  To keep several chunks in flight the caller
+ * opens a burst with esim_free_begin(k) (k = steps it may cover), repeats { esim_future_infected; all-reduce F;
+ * esim_free_enqueue } as often as it likes -- each round enqueues one whole chunk, which is a no-op on EVERY
+ * shard when it cannot run in the one-pass form or would reach the step that starts vaccinating -- and calls
+ * esim_free_collect(&done) once: done = steps the burst advanced (the same on all shards).
  * esim_set_pipeline(ctx, level): 0 = sequential steps only; 1 = chunks run as one kernel per step (k_pipe);
  * 2 (default) = additionally, when the chunk's marks fit the hash map, ALL steps of a chunk are drawn in one
  * pass (a citizen's exposure step is the earliest step at which any of its draws succeeds -- one atomicMin on
@@ -162,6 +169,9 @@ int  esim_exchange_buffer(esim_ctx *ctx, int which /* 0 = A, 1 = B, 2 = F */, vo
  * since the last call (measured while kernel timing is enabled). */
 int  esim_future_infected(esim_ctx *ctx);
 int  esim_run_free(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_done);
+int  esim_free_begin(esim_ctx *ctx, uint32_t n_steps);
+int  esim_free_enqueue(esim_ctx *ctx);
+int  esim_free_collect(esim_ctx *ctx, uint32_t *n_done);
 int  esim_set_pipeline(esim_ctx *ctx, int level);
 int  esim_chunk_timing(esim_ctx *ctx, double *total_ms, uint64_t *steps, uint64_t *chunks);
 /* Record log read-back for split-phase runs (records first..first+n-1, 1-based time steps). */

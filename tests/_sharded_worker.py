@@ -25,6 +25,8 @@ def main():
     pop = Population.synthetic("york", **cfg["spec"])
     ep = _lib.default_params(**cfg["params"])
     dev = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank in cfg.get("tiny_hash_ranks", ()):   # this rank's chunks never fit the one-pass form
+        os.environ["ESIM_HASH_LOG2"] = "4"
     if cfg.get("cuts") == "even":              # cuts through school catchments: shared buildings, coupled steps
         sim = ShardedSimulator(pop, rank, world, ep, device_index=dev, cuts=pop.even_cuts(world))
         assert sim.population.n_shared_buildings > 0 and not sim.mode_free
@@ -36,6 +38,8 @@ def main():
     else:                                      # commuter-free cuts: decoupled batches until vaccination starts
         sim = ShardedSimulator(pop, rank, world, ep, device_index=dev)
         assert sim.population.n_shared_buildings == 0 and sim.mode_free
+    if "burst_max" in cfg and sim.sharded:
+        sim.burst_max = cfg["burst_max"]
     orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
     done = 0
     while done < cfg["steps"]:

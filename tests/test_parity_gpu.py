@@ -124,6 +124,14 @@ def test_big_routes_and_u8_truncation():
                    lockdown_threshold=0.95, mask_pt_threshold=0.2, mask_everywhere_threshold=0.4, seed=5)
 
 
+def test_route_longer_than_the_one_pass_limit():
+    # a single Output Area: one route of several thousand riders (> CHUNK_ROUTE_MAX = 2048), so no chunk may take the
+    # one-pass form and level 2 has to fall back to one kernel per step by itself
+    pop = Population.synthetic("york", n_citizens=12000, n_areas=1, citizens_per_school=6000, n_seeds=30,
+                               p_public_transport=0.6)
+    run_both(pop, 400, check_state_every=200, small_limits=("tp", None), exposure_chance=0.01, seed=23)
+
+
 def test_lockdown_freeze_on_a_bus_hour():
     # lockdown decided at the end of an hour-8 step keeps riders on the bus every step (Q8)
     pop = Population.synthetic("york", n_citizens=4000, n_areas=8, citizens_per_school=2000, n_seeds=30)

@@ -72,6 +72,25 @@ def test_two_shards_decoupled_then_coupled_match_oracle():
     assert all("ok" in o for o in outs)
 
 
+def test_two_shards_decoupled_chunk_by_chunk_match_oracle():
+    # the same without bursts: one host wait per chunk (esim_run_free)
+    cfg = dict(backend="gloo", cuts="clean", expect_both_modes=True, burst_max=0,
+               spec=dict(n_citizens=12000, n_areas=40, citizens_per_school=2500, n_seeds=16),
+               params=AGGRESSIVE, steps=600, chunk=150)
+    outs = launch(2, cfg)
+    assert all("ok" in o for o in outs)
+
+
+def test_two_shards_one_without_room_for_one_pass_chunks_match_oracle():
+    # rank 1's hash map is too small for any one-pass chunk: buffer F's last word tells rank 0, speculative chunks are
+    # no-ops on both, and both fall back to the per-step form of the chunk in lockstep
+    cfg = dict(backend="gloo", cuts="clean", expect_both_modes=True, tiny_hash_ranks=[1],
+               spec=dict(n_citizens=12000, n_areas=40, citizens_per_school=2500, n_seeds=16),
+               params=dict(AGGRESSIVE, seed=5), steps=450, chunk=150)
+    outs = launch(2, cfg)
+    assert all("ok" in o for o in outs)
+
+
 def test_three_generated_shards_match_oracle():
     # every rank generates only its own shard (esim_synth_create_shard); the oracle runs the whole world
     cfg = dict(backend="gloo", cuts="generated", spec=dict(n_citizens=15000, n_areas=48, citizens_per_school=2500, n_seeds=16),
