@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libesim.so")
+LIB_PATH = os.environ.get("ESIM_LIB") or os.path.join(_HERE, "libesim.so")   # ESIM_LIB: a diagnostics build of the same library
 
 OK = 0
 ERRORS = {-1: "EINVAL", -2: "ENODEVICE", -3: "ENOMEM", -4: "ESTATE", -5: "ERANGE", -6: "ESIM"}

@@ -260,7 +260,11 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     route_off.push_back((uint32_t)pairs.size());
     bool any_big = false;
     uint32_t max_route = 0;
-    for (uint32_t r = 0; r < n_routes; ++r) { any_big |= route_off[r + 1] - route_off[r] > 64; max_route = std::max(max_route, route_off[r + 1] - route_off[r]); }
+    for (uint32_t r = 0; r < n_routes; ++r) {
+        const uint32_t sz = route_off[r + 1] - route_off[r];
+        max_route = std::max(max_route, sz);
+        if (sz > 64) { any_big = true; for (uint32_t q = route_off[r]; q < route_off[r + 1]; ++q) fl[riders[q]] |= FL_BIG_ROUTE; }
+    }
     { std::vector<std::pair<uint64_t, uint32_t>>().swap(pairs); }
 
     // ---- static member lists (the occupant lists the reference keeps per building:
@@ -330,8 +334,10 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if ((rc = dev_alloc(c, &d.hitems, d.items_cap))) return rc;
         if ((rc = dev_alloc(c, &d.item_rec, d.items_cap))) return rc;
         if ((rc = dev_alloc(c, &d.vec, (size_t)d.items_cap * FREE_MAX))) return rc;
-        // deferred units: the most a chunk can ask for is every long member list marked in every step
-        size_t units = 1024;
+        // deferred units: SUBQ queues; a queue that is full makes its producer draw the list itself, so the size is a
+        // matter of speed only.  Room for the smaller of: every long member list marked in every step; a quarter of the
+        // citizens -- four times over, since the queues fill unevenly.
+        size_t units = 0;
         auto add_lists = [&](const std::vector<uint32_t> &off) {
             for (size_t i = 0; i + 1 < off.size(); ++i) {
                 const size_t pairs = (size_t)(off[i + 1] - off[i]) * FREE_MAX;
@@ -339,14 +345,19 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
             }
         };
         add_lists(res_off); add_lists(wrk_off); add_lists(room_off);
-        if (units > 0xFFFFFFF0ull) return fail(c, ESIM_ERANGE, "population too large for the unit table");
-        d.units_cap = (uint32_t)units;
-        if ((rc = dev_alloc(c, &d.unit_item, d.units_cap))) return rc;
-        if ((rc = dev_alloc(c, &d.unit_lo, d.units_cap))) return rc;
-        if ((rc = dev_alloc(c, &d.route_pairs, d.items_cap))) return rc;
-        if ((rc = dev_alloc(c, &d.route_pairs_big, d.items_cap))) return rc;
+        units = std::min<size_t>(units, (size_t)N / 4u + 65536u);
+        d.unit_qcap = (uint32_t)std::max<size_t>(1024, units * 4u / SUBQ);
+        if ((rc = dev_alloc(c, &d.unit_item, (size_t)d.unit_qcap * SUBQ))) return rc;
+        if ((rc = dev_alloc(c, &d.unit_lo, (size_t)d.unit_qcap * SUBQ))) return rc;
+        if ((rc = dev_alloc(c, &d.route_pairs, (size_t)d.items_cap * 2u))) return rc;
+        if ((rc = dev_alloc(c, &d.route_pairs_big, (size_t)d.items_cap * 2u))) return rc;
+        if ((rc = dev_alloc(c, &d.pair_cnt, 16384u))) return rc;
+        if ((rc = dev_alloc(c, &d.hot, (size_t)HOT_COUNT * HOT_STRIDE))) return rc;
+        HIP_TRY(c, hipMemset(d.hot, 0, sizeof(uint32_t) * HOT_COUNT * HOT_STRIDE));
+        HIP_TRY(c, hipMemset(d.pair_cnt, 0, sizeof(uint32_t) * 16384u));
         HIP_TRY(c, hipMemset(d.hval, 0xFF, sizeof(uint32_t) * cap));
-        if ((rc = dev_alloc(c, &d.newexp, (size_t)N + 1))) return rc;
+        d.newexp_cap = N / SUBQ + 1u;                 // citizens with the same id & 63: nobody is listed twice in a chunk
+        if ((rc = dev_alloc(c, &d.newexp, (size_t)d.newexp_cap * SUBQ))) return rc;
         if ((rc = dev_alloc(c, &d.cursor, FREE_MAX))) return rc;
         HIP_TRY(c, hipMemset(d.hkey, 0xFF, sizeof(unsigned long long) * cap));
         HIP_TRY(c, hipMemset(d.vec, 0, sizeof(uint32_t) * (size_t)d.items_cap * FREE_MAX));
@@ -387,6 +398,10 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     d.n_shared_bld = pop->n_shared_buildings; d.n_shared_room = pop->n_shared_rooms;
     if ((rc = dev_upload(c, &d.shared_bld, pop->shared_building_local, pop->n_shared_buildings))) return rc;
     if ((rc = dev_upload(c, &d.shared_room, pop->shared_room_local, pop->n_shared_rooms))) return rc;
+#ifdef ESIM_WAVE_PROFILE
+    if ((rc = dev_alloc(c, &d.prof_buf, (size_t)16384 * 16))) return rc;
+    HIP_TRY(c, hipMemset(d.prof_buf, 0, sizeof(uint32_t) * 16384 * 16));
+#endif
     c->xa_n = XA_HEADER + (size_t)d.n_shared_bld + d.n_shared_room;
     c->xb_n = XB_HEADER + VACC_BATCH / 32u;
     if ((rc = dev_alloc(c, &d.xa, c->xa_n))) return rc;
@@ -402,6 +417,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     c->grid_infected = 1024;
     c->grid_expose = 1024;
     if (const char *e = std::getenv("ESIM_GRID_INFECTED")) c->grid_infected = (uint32_t)std::max(1, std::atoi(e));   // tuning knobs
+    if (const char *e = std::getenv("ESIM_GRID_CHUNK")) c->grid_chunk = (uint32_t)std::min(4096, std::max(16, std::atoi(e) / 16 * 16));   // whole groups of 64 wavefronts
     if (const char *e = std::getenv("ESIM_GRID_EXPOSE")) c->grid_expose = (uint32_t)std::max(1, std::atoi(e));
     c->uploaded = true;
     return esim_reset(ctx);
@@ -598,6 +614,7 @@ void enqueue_parallel_chunk(esim_ctx_impl *c)
     Dev &d = c->d;
     hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    if (d.max_route > 64u) hipLaunchKernelGGL(k_chunk_routes_big, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_finish, dim3(1), dim3(FIN_TPB), 0, c->stream, d);
@@ -884,6 +901,20 @@ extern "C" int esim_debug_counters(esim_ctx *ctx, uint32_t out[16])
     std::memcpy(out, v, sizeof v);
     return ESIM_OK;
 }
+
+#ifdef ESIM_WAVE_PROFILE
+// diagnostics build only (not in include/esim.h): rows of per-wavefront timers, and the timer's rate in kHz
+extern "C" int esim_prof_read(esim_ctx *ctx, uint32_t *out, uint32_t n_words, int *clock_khz)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded || !out) return ESIM_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->d.prof_buf, sizeof(uint32_t) * std::min<uint32_t>(n_words, 16384u * 16u), hipMemcpyDeviceToHost));
+    if (clock_khz) HIP_TRY(c, hipDeviceGetAttribute(clock_khz, hipDeviceAttributeWallClockRate, c->P.device));
+    return ESIM_OK;
+}
+#endif
 
 extern "C" int esim_set_small_step_limit(esim_ctx *ctx, uint32_t max_infected)
 {

@@ -32,6 +32,7 @@
 #define FL_SAME_AREA      0x04u      // area(work building) == area(home building)  (Q4, simulator.rs:324)
 #define FL_WORK_SCHOOL    0x08u      // work building is a School (room draws, building.rs:494-522)
 #define FL_HAS_WORK       0x10u      // workplace_code != household_code
+#define FL_BIG_ROUTE      0x20u      // rides a route of more than 64 riders (ranked by a workgroup, not by a wavefront)
 
 #define VACC_BATCH 4096u             // vaccination candidates examined per batch
 #define VACC_TABLE 16384u            // LDS hash-set slots (>= max rate + VACC_BATCH, power of two)
@@ -79,7 +80,7 @@ struct Ctrl {
 
 // An item of a time-parallel chunk: a building (a = residents, b = workers, aux = type), a school room (a =
 // participants, aux = its school building) or a route.
-struct ItemRec { uint32_t id, a_lo, a_hi, b_lo, b_hi, aux, pad0, pad1; };
+struct ItemRec { uint32_t id, a_lo, a_hi, b_lo, b_hi, aux, link, pad1; };   // link: a room's school item
 
 // What is in force during one step of a pipelined chunk (k_decide fills dec[0..chunk_ok]).
 struct Decision {
@@ -117,11 +118,15 @@ struct Dev {
     struct ItemRec *item_rec;   // [items_cap] what the draw pass needs of an item, written at claim time
     uint32_t *vec;              // [items_cap][FREE_MAX] infected standing in the item in each step of the chunk
     uint32_t items_cap;
-    uint32_t *unit_item, *unit_lo;  // [units_cap] item | kind << 30, first pair of the unit
-    uint32_t *route_pairs;      // [items_cap] route item << 7 | step of the chunk (routes of <= 64 riders)
-    uint32_t *route_pairs_big;  // [items_cap]
-    uint32_t units_cap;
-    uint32_t *newexp;           // [n] citizens exposed in the chunk
+    uint32_t *unit_item, *unit_lo;  // [SUBQ][unit_qcap] item | kind << 30 (UNIT_NOOP: skip), first pair of the unit
+    uint32_t *route_pairs;      // [2 * items_cap] route << 7 | step of the chunk, routes of <= 64 riders: wavefront w of
+                                // k_chunk_marks owns entries [w * 2 * items_per_wave, ...), pair_cnt[w] of them are filled
+    uint32_t *pair_cnt;         // [wavefronts of k_chunk_marks]
+    uint32_t *route_pairs_big;  // [2 * items_cap] the same for longer routes, one shared list
+    uint32_t unit_qcap;
+    uint32_t *newexp;           // [SUBQ][newexp_cap] citizens exposed in the chunk, by id & 63
+    uint32_t newexp_cap;
+    uint32_t *hot;              // [HOT_COUNT * HOT_STRIDE] the counters of the lists above
     uint32_t *cursor;           // [FREE_MAX] per-step write cursors into the log
     uint32_t max_route;         // riders of the largest route
     uint32_t *hist;             // [TE_SLOTS] citizens per exposure time (census without a pass over citizens)
@@ -146,6 +151,9 @@ struct Dev {
     uint32_t n_shared_bld, n_shared_room;
     const int32_t *shared_bld, *shared_room;
     uint32_t *xa, *xb, *xf;             // exchange buffers A, B and the future-infected vector
+#ifdef ESIM_WAVE_PROFILE
+    uint32_t *prof_buf;                 // diagnostics build only: [wavefronts][16] timers of the last chunk (tools/wave_profile.py)
+#endif
     uint32_t xf_n;                      // steps buffer F covers (min(FREE_MAX, exposed_time + 1)); word xf[xf_n]: shards whose
                                         // chunk does not fit the one-pass form
 };
@@ -159,5 +167,15 @@ struct Dev {
 // draw the chunk in one pass
 #define FREE_MAX 96u
 #define HKEY_EMPTY 0xFFFFFFFFFFFFFFFFull
-#define UNIT_PAIRS 1024u           // (member, marked step) pairs per deferred unit of a long member list
+// Shared lists of the chunk pass are split so that no single address takes more than a few atomics per pass (atomics on
+// one address are served one at a time, ~10 ns each): every counter has a 128-byte line of its own in Dev::hot.
+#define HOT_STRIDE 32u             // uint32 per counter
+#define SUBQ 64u                   // sub-lists per shared list
+#define HOT_NEWEXP 0u              // [SUBQ] citizens exposed in the chunk, by citizen id & 63
+#define HOT_UNITS 64u              // [SUBQ] deferred units, by producing wavefront & 63
+#define HOT_BIGPAIRS 128u          // (route, bus step) pairs of routes with more than 64 riders
+#define HOT_COUNT 129u
+#define UNIT_NOOP 0xFFFFFFFFu
+#define CHUNK_BUS_STEPS 8u         // a one-pass chunk has at most this many steps with riders on a bus
+#define UNIT_PAIRS 256u            // (member, marked step) pairs per deferred unit of a long member list
 #define CHUNK_ROUTE_MAX 2048u      // routes up to this many riders are ranked in LDS by the time-parallel pass

@@ -113,6 +113,32 @@ __device__ __forceinline__ void append(uint32_t *list, uint32_t *len, uint32_t v
     list[atomicAdd(len, 1u)] = v;
 }
 
+// The same for all lanes of a wavefront that are active here and have `pred` set, with ONE atomic on the shared
+// length (atomics on a single address are served one at a time, ~10 ns each: thousands of single appends per pass
+// would be its critical path).  `len` must be the same for all of them.
+__device__ __forceinline__ void append_wave(uint32_t *list, uint32_t *len, uint32_t v, bool pred)
+{
+    const unsigned long long m = __ballot(pred);
+    if (!pred) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(len, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
+}
+
+// Diagnostics build (make prof): every wavefront of the chunk-pass kernels stores its timers in its own row of
+// d.prof_buf -- no atomics, so the measurement does not serialise the kernel it measures.
+#ifdef ESIM_WAVE_PROFILE
+#define PROF_ROW 16u
+#define PROF_NOW() ((uint32_t)wall_clock64())
+#define PROF_PUT(d, i, v) do { if ((threadIdx.x & 63u) == 0) (d).prof_buf[(size_t)(((blockIdx.x * TPB + threadIdx.x) >> 6)) * PROF_ROW + (i)] = (uint32_t)(v); } while (0)
+#else
+#define PROF_NOW() 0u
+#define PROF_PUT(d, i, v) do { (void)sizeof(v); } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------- k_infected
 // The Infected citizens of step t are the log slice with exposure step in
 // [t - exposed_time - 1 - infected_time, t - exposed_time - 1].  simulator.rs:181-198: a rider
@@ -503,7 +529,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_future(Dev d, uint32_t max_ahead, u
         // Can this shard draw the chunk in one pass?  A citizen marks at most its home, its work building, its room and
         // its route.  The word after the census counts the shards that cannot, so that after the all-reduce every shard
         // takes the same form of the chunk (speculatively enqueued chunks advance on all shards or on none).
-        const bool fits = d.items_cap && d.max_route <= CHUNK_ROUTE_MAX &&
+        const bool fits = d.items_cap && d.max_route <= CHUNK_ROUTE_MAX && d.n_routes < (1u << 25) &&
                           (unsigned long long)pairs * 4ull + 65536ull <= (unsigned long long)d.items_cap;
         d.xf[d.xf_n] = fits ? 0u : 1u;
     }
@@ -629,9 +655,14 @@ __global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32
         const uint32_t bd_last = jn ? __shfl(jn - 1u < 64u ? mine[0].bus_dir : mine[1].bus_dir, (int)((jn - 1u) & 63u), 64) : bus_init;
         if (lane == 0) d.dec[jn] = Decision{ lock_after, mask_after, aw_last, bd_last };
     }
+    const unsigned long long bus_m0 = __ballot(lane < n_ok && mine[0].bus_dir != 0u), bus_m1 = __ballot(64u + lane < n_ok && mine[1].bus_dir != 0u);
+    for (uint32_t i = lane; i < HOT_COUNT; i += 64u) d.hot[i * HOT_STRIDE] = 0u;
     if (lane == 0) {
         ctrl->chunk_ok = n_ok; ctrl->chunk_t0 = t0;
-        ctrl->chunk_parallel = (allow_parallel && d.xf[d.xf_n] == 0u) ? 1u : 0u;
+        // riders are on a bus in at most CHUNK_BUS_STEPS steps of a one-pass chunk (two a day unless a lockdown froze them
+        // there, Q8): that bounds the (route, bus step) pairs a wavefront of k_chunk_marks can register.  The same on all shards.
+        const uint32_t bus_steps = (uint32_t)(__popcll(bus_m0) + __popcll(bus_m1));
+        ctrl->chunk_parallel = (allow_parallel && d.xf[d.xf_n] == 0u && bus_steps <= CHUNK_BUS_STEPS) ? 1u : 0u;
         ctrl->n_items = 0u; ctrl->n_newexp = 0u; ctrl->n_units = 0u; ctrl->unit_next = 0u; ctrl->n_route_pairs = 0u; ctrl->n_route_pairs_big = 0u;
     }
     d.cursor[lane] = 0u;
@@ -769,20 +800,28 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
     uint32_t next_id = wave * per_wave;
     const Decision q0 = lane < n ? d.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
     const Decision q1 = 64u + lane < n ? d.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
+    // lanes 0..3 own one key each: home building, work building, room, route.  The entry after this one is fetched
+    // (log entry, word, the lane's key source) before the work on this one: the hash claim's round trips overlap it.
+    const uint32_t *key_src = lane == 0 ? d.home : lane == 1 ? d.work : lane == 2 ? d.room : d.route_of;
+    const uint32_t pm0 = PROF_NOW();
+    uint32_t p_entries = 0u;
+    uint32_t my_pairs = 0u;                                                   // (route, bus step) pairs this wavefront registered
+    uint32_t c_n = 0u, w_n = 0u, k_n = 0u;
+    if (i0 + wave < i1) { c_n = d.log[i0 + wave]; w_n = d.cit[c_n]; if (lane < 4u) k_n = key_src[c_n]; }
     for (uint32_t e = i0 + wave; e < i1; e += n_waves) {
-        const uint32_t c = d.log[e];
-        const uint32_t w = d.cit[c];
+        const uint32_t w = w_n, ksrc = k_n;
+        if (e + n_waves < i1) { c_n = d.log[e + n_waves]; w_n = d.cit[c_n]; if (lane < 4u) k_n = key_src[c_n]; }
         const uint32_t p0 = lane < n ? where_in_step(d, w, t0 + lane, q0) : 0u;
         const uint32_t p1 = 64u + lane < n ? where_in_step(d, w, t0 + 64u + lane, q1) : 0u;
         const bool any_home = __any((p0 | p1) & 1u), any_work = __any((p0 | p1) & 2u), any_bus = __any((p0 | p1) & 4u);
         const bool school = w & FL_WORK_SCHOOL;
         if (!any_home && !any_work && !any_bus) continue;
-        // lanes 0..3 own one key each: home building, work building, room, route
+        ++p_entries;
         unsigned long long key = HKEY_EMPTY;
-        if (lane == 0 && any_home) key = d.home[c];
-        if (lane == 1 && any_work) key = d.work[c];
-        if (lane == 2 && any_work && school) key = (unsigned long long)d.n_bld + d.room[c];
-        if (lane == 3 && any_bus) key = (unsigned long long)d.n_bld + d.n_room + d.route_of[c];
+        if (lane == 0 && any_home) key = ksrc;
+        if (lane == 1 && any_work) key = ksrc;
+        if (lane == 2 && any_work && school) key = (unsigned long long)d.n_bld + ksrc;
+        if (lane == 3 && any_bus) key = (unsigned long long)d.n_bld + d.n_room + ksrc;
         uint32_t v = 0xFFFFFFFFu, slot = 0u;
         bool pending = false, claimed = false;
         if (key != HKEY_EMPTY) claimed = item_probe(d, ctrl, key, slot, pending);
@@ -793,7 +832,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
             __hip_atomic_store(&d.hval[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // claims are published here ...
             // what the draw pass needs of the item (read by later kernels only)
             const uint32_t id = (uint32_t)key;
-            ItemRec rec = { id, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+            ItemRec rec = { id, 0u, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u };
             if (id < d.n_bld) { rec.a_lo = d.res_off[id]; rec.a_hi = d.res_off[id + 1]; rec.b_lo = d.wrk_off[id]; rec.b_hi = d.wrk_off[id + 1]; rec.aux = d.bld_type[id]; }
             else if (id < d.n_bld + d.n_room) { const uint32_t r = id - d.n_bld; rec.a_lo = d.room_off[r]; rec.a_hi = d.room_off[r + 1]; rec.aux = d.room_bld[r]; }
             d.item_rec[v] = rec;
@@ -802,20 +841,41 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         __builtin_amdgcn_wave_barrier();
         if (pending) v = item_wait(d, ctrl, slot);                            // ... before any lane waits for somebody else's
         const uint32_t v_home = __shfl(v, 0, 64), v_work = __shfl(v, 1, 64), v_room = __shfl(v, 2, 64), v_bus = __shfl(v, 3, 64);
+        if (lane == 2 && claimed) d.item_rec[v].link = v_work;                // a room's record points at its school's item
         if (p0 & 1u) atomicAdd(&d.vec[(size_t)v_home * FREE_MAX + lane], 1u);
         if (p1 & 1u) atomicAdd(&d.vec[(size_t)v_home * FREE_MAX + 64u + lane], 1u);
         if (p0 & 2u) { atomicAdd(&d.vec[(size_t)v_work * FREE_MAX + lane], 1u); if (school) atomicAdd(&d.vec[(size_t)v_room * FREE_MAX + lane], 1u); }
         if (p1 & 2u) { atomicAdd(&d.vec[(size_t)v_work * FREE_MAX + 64u + lane], 1u); if (school) atomicAdd(&d.vec[(size_t)v_room * FREE_MAX + 64u + lane], 1u); }
         // the first Infected rider of a (route, step) registers the pair: each gets a workgroup of its own in k_chunk_draw
         if (any_bus) {
-            const uint32_t rt = d.route_of[c];
-            const bool small = d.route_off[rt + 1] - d.route_off[rt] <= 64u;
-            uint32_t *list = small ? d.route_pairs : d.route_pairs_big;
-            uint32_t *len = small ? &ctrl->n_route_pairs : &ctrl->n_route_pairs_big;
-            if ((p0 & 4u) && atomicAdd(&d.vec[(size_t)v_bus * FREE_MAX + lane], 1u) == 0u) append(list, len, (v_bus << 7) | lane);
-            if ((p1 & 4u) && atomicAdd(&d.vec[(size_t)v_bus * FREE_MAX + 64u + lane], 1u) == 0u) append(list, len, (v_bus << 7) | (64u + lane));
+            const bool f0 = (p0 & 4u) && atomicAdd(&d.vec[(size_t)v_bus * FREE_MAX + lane], 1u) == 0u;
+            const bool f1 = (p1 & 4u) && atomicAdd(&d.vec[(size_t)v_bus * FREE_MAX + 64u + lane], 1u) == 0u;
+            const uint32_t rt = __shfl(ksrc, 3, 64);                          // the route itself, not its item: saves the pass a hop
+            const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
+            const uint32_t add = (uint32_t)(__popcll(m0) + __popcll(m1));     // <= CHUNK_BUS_STEPS (k_decide)
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            if (!(w & FL_BIG_ROUTE)) {
+                // this wavefront's own stretch of the list: no shared counter
+                uint32_t *list = d.route_pairs + (size_t)wave * 2u * per_wave;
+                if (my_pairs + add <= 2u * per_wave) {
+                    if (f0) list[my_pairs + (uint32_t)__popcll(m0 & lt)] = (rt << 7) | lane;
+                    if (f1) list[my_pairs + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1 & lt)] = (rt << 7) | (64u + lane);
+                    my_pairs += add;
+                } else if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE);
+            } else if (add) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&d.hot[HOT_BIGPAIRS * HOT_STRIDE], add);
+                base = __shfl(base, 0, 64);
+                if (base + add <= 2u * d.items_cap) {
+                    if (f0) d.route_pairs_big[base + (uint32_t)__popcll(m0 & lt)] = (rt << 7) | lane;
+                    if (f1) d.route_pairs_big[base + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1 & lt)] = (rt << 7) | (64u + lane);
+                } else if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE);
+            }
         }
     }
+    if (lane == 0) d.pair_cnt[wave] = my_pairs;
+    const uint32_t pm1 = PROF_NOW();
+    PROF_PUT(d, 8, pm0); PROF_PUT(d, 9, pm1); PROF_PUT(d, 10, p_entries);
 }
 
 // A successful draw of citizen m in step s (bus: on public transport).
@@ -823,12 +883,17 @@ __device__ __forceinline__ void expose_min(const Dev &d, Ctrl *ctrl, uint32_t m,
 {
     const uint32_t cand = CW_MAKE(s + TE_BIAS, bus | (w & CW_FLAGS));
     const uint32_t prev = atomicMin(&d.cit[m], cand);
-    if (cand < prev && CW_TE(prev) == TE_SUSCEPTIBLE) append(d.newexp, &ctrl->n_newexp, m);   // first exposure in this chunk
+    if (cand < prev && CW_TE(prev) == TE_SUSCEPTIBLE) {                       // first exposure in this chunk
+        const uint32_t r = m & (SUBQ - 1u);
+        d.newexp[(size_t)r * d.newexp_cap + atomicAdd(&d.hot[(HOT_NEWEXP + r) * HOT_STRIDE], 1u)] = m;
+    }
 }
 
 struct ChunkShared {
     Decision dec[FREE_MAX];
     uint64_t thr[512];
+};
+struct RouteShared {
     uint32_t s_key[CHUNK_ROUTE_MAX];
     uint16_t s_bus[CHUNK_ROUTE_MAX];
     uint8_t s_inf[CHUNK_ROUTE_MAX];
@@ -840,8 +905,10 @@ struct WaveScratch { uint32_t cnt[FREE_MAX]; uint32_t sch[FREE_MAX]; uint32_t me
 // spread densely over the 64 lanes (the draws are Philox-bound -- 20 quarter-rate multiplies each -- so idle lanes
 // are what costs).  ws.steps: the item's marked steps in order, S of them; ws.cnt / ws.sch: the item's / the school's
 // Infected per step.  kind 0 residents, 1 workers, 2 room participants.
+// pre_m / pre_w: members lo + lane of the list and their words when the caller has already fetched them (have_pre).
 __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, WaveScratch &ws, const uint32_t *idx,
-                                             uint32_t lo, uint32_t p_lo, uint32_t p_hi, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0)
+                                             uint32_t lo, uint32_t p_lo, uint32_t p_hi, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0,
+                                             bool have_pre = false, uint32_t pre_m = 0u, uint32_t pre_w = 0u)
 {
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
     // members touched by the pairs [p_lo, p_hi): staged in LDS 64 at a time -- every member recurs once per marked step
@@ -849,9 +916,12 @@ __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const Chu
     for (uint32_t mb = m_first; mb <= m_last; mb += 64u) {
         __builtin_amdgcn_wave_barrier();
         if (mb + lane <= m_last) {
-            const uint32_t m = idx ? idx[lo + mb + lane] : lo + mb + lane;
-            ws.mem_id[lane] = m;
-            ws.mem_w[lane] = d.cit[m];
+            if (have_pre && mb == 0u) { ws.mem_id[lane] = pre_m; ws.mem_w[lane] = pre_w; }
+            else {
+                const uint32_t m = idx ? idx[lo + mb + lane] : lo + mb + lane;
+                ws.mem_id[lane] = m;
+                ws.mem_w[lane] = d.cit[m];
+            }
         }
         __builtin_amdgcn_wave_barrier();
         const uint32_t q_lo = max(p_lo, mb * S), q_hi = min(p_hi, (mb + 64u) * S);
@@ -881,6 +951,17 @@ __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const Chu
 }
 
 // The marked steps of item v, in order, and its per-step counts, into this wavefront's scratch.  Returns S.
+__device__ __forceinline__ uint32_t item_steps_regs(uint32_t c0, uint32_t c1, uint32_t lane, WaveScratch &ws)
+{
+    ws.cnt[lane] = c0;
+    if (lane < FREE_MAX - 64u) ws.cnt[64u + lane] = c1;
+    const unsigned long long b0 = __ballot(c0 != 0u), b1 = __ballot(c1 != 0u);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (c0) ws.steps[__popcll(b0 & lt)] = (uint8_t)lane;
+    if (c1) ws.steps[__popcll(b0) + __popcll(b1 & lt)] = (uint8_t)(64u + lane);
+    return (uint32_t)(__popcll(b0) + __popcll(b1));
+}
+
 __device__ __forceinline__ uint32_t item_steps(const Dev &d, uint32_t v, uint32_t lane, uint32_t n, WaveScratch &ws)
 {
     const uint32_t c0 = lane < n ? d.vec[(size_t)v * FREE_MAX + lane] : 0u;
@@ -894,9 +975,9 @@ __device__ __forceinline__ uint32_t item_steps(const Dev &d, uint32_t v, uint32_
     return (uint32_t)(__popcll(b0) + __popcll(b1));
 }
 
-__device__ __forceinline__ void school_counts(const Dev &d, uint32_t school_bld, uint32_t lane, uint32_t n, WaveScratch &ws)
+__device__ __forceinline__ void school_counts(const Dev &d, uint32_t v_sch, uint32_t lane, uint32_t n, WaveScratch &ws)
 {
-    const uint32_t v_sch = item_find(d, school_bld);                          // infected in the whole school, per step
+    // v_sch: the item of the room's school (k_chunk_marks left it in the room's record): infected in the whole school, per step
     ws.sch[lane] = (v_sch != 0xFFFFFFFFu && lane < n) ? d.vec[(size_t)v_sch * FREE_MAX + lane] : 0u;
     if (lane < FREE_MAX - 64u) ws.sch[64u + lane] = (v_sch != 0xFFFFFFFFu && 64u + lane < n) ? d.vec[(size_t)v_sch * FREE_MAX + 64u + lane] : 0u;
 }
@@ -904,22 +985,45 @@ __device__ __forceinline__ void school_counts(const Dev &d, uint32_t school_bld,
 // Lists with more pairs than this are cut into units that any wavefront can take (k_chunk_units), so that one
 // 200-member workplace does not keep a single wavefront busy while the chip idles.
 __device__ __forceinline__ void list_or_units(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, WaveScratch &ws, const uint32_t *idx,
-                                              uint32_t lo, uint32_t hi, uint32_t v, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0)
+                                              uint32_t lo, uint32_t hi, uint32_t v, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0,
+                                              bool have_pre = false, uint32_t pre_m = 0u, uint32_t pre_w = 0u)
 {
     const uint32_t pairs = (hi - lo) * S;
     if (pairs == 0) return;
-    if (pairs <= UNIT_PAIRS) { member_pairs(d, ctrl, sm, ws, idx, lo, 0u, pairs, lane, kind, S, t0); return; }
+    if (pairs <= UNIT_PAIRS) { member_pairs(d, ctrl, sm, ws, idx, lo, 0u, pairs, lane, kind, S, t0, have_pre, pre_m, pre_w); return; }
     const uint32_t n_units = (pairs + UNIT_PAIRS - 1u) / UNIT_PAIRS;
+    const uint32_t r = ((blockIdx.x * TPB + threadIdx.x) >> 6) & (SUBQ - 1u);  // this wavefront's queue
     uint32_t start = 0;
-    if (lane == 0) start = atomicAdd(&ctrl->n_units, n_units);
+    if (lane == 0) start = atomicAdd(&d.hot[(HOT_UNITS + r) * HOT_STRIDE], n_units);
     start = __shfl(start, 0, 64);
+    uint32_t *q_item = d.unit_item + (size_t)r * d.unit_qcap, *q_lo = d.unit_lo + (size_t)r * d.unit_qcap;
+    if (start + n_units > d.unit_qcap) {
+        // queue full: what was reserved of it becomes no-ops and the list is drawn here
+        for (uint32_t i = lane; i < n_units && start + i < d.unit_qcap; i += 64u) q_item[start + i] = UNIT_NOOP;
+        member_pairs(d, ctrl, sm, ws, idx, lo, 0u, pairs, lane, kind, S, t0, have_pre, pre_m, pre_w);
+        return;
+    }
     for (uint32_t i = lane; i < n_units; i += 64u) {
-        if (start + i >= d.units_cap) { ctrl->error = (uint32_t)(-ESIM_ERANGE); break; }
-        d.unit_item[start + i] = v | (kind << 30);
-        d.unit_lo[start + i] = i * UNIT_PAIRS;
+        q_item[start + i] = v | (kind << 30);
+        q_lo[start + i] = i * UNIT_PAIRS;
     }
 }
 
+// What a wavefront needs of item v before it can start on it; depends on v alone, so the fetch of the next item is
+// issued before the work on the current one (the pass is bound by chains of dependent loads, not by bandwidth).
+struct ItemFetch { uint32_t slot, id, a_lo, a_hi, b_lo, b_hi, aux, link, c0, c1; };
+__device__ __forceinline__ ItemFetch fetch_item(const Dev &d, uint32_t v, uint32_t lane, uint32_t n)
+{
+    ItemFetch f;
+    f.slot = d.hitems[v];
+    const ItemRec r = d.item_rec[v];
+    f.id = r.id; f.a_lo = r.a_lo; f.a_hi = r.a_hi; f.b_lo = r.b_lo; f.b_hi = r.b_hi; f.aux = r.aux; f.link = r.link;
+    f.c0 = lane < n ? d.vec[(size_t)v * FREE_MAX + lane] : 0u;
+    f.c1 = 64u + lane < n ? d.vec[(size_t)v * FREE_MAX + 64u + lane] : 0u;
+    return f;
+}
+
+#define PAIR_SPREAD 1237u
 // apply_exposures (simulator.rs:262-405) for every item and every step of the chunk.
 __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
 {
@@ -928,43 +1032,85 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     Ctrl *ctrl = d.ctrl;
     const uint32_t t0 = ctrl->chunk_t0, n = ctrl->chunk_ok;
     if (!ctrl->chunk_parallel || n == 0u) return;
-    for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
-    for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
-    __syncthreads();
     const uint32_t n_items = min(ld(&ctrl->n_items), d.items_cap);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    const uint32_t pt0 = PROF_NOW();
+    uint32_t p_items = 0u, p_item_max = 0u;
+    // the items claimed by the wavefront of the same index in k_chunk_marks (same grid): ids [wave * per_wave, ...), handed
+    // out in order, so the first unused id ends the list.  (Striding over all ids instead would pile the items onto
+    // the few wavefronts whose index matches the low ids of every range.)
+    const uint32_t per_wave = ld(&ctrl->items_per_wave);
+    const uint32_t v_lo = wave * per_wave, v_hi = min(v_lo + per_wave, n_items);
+    ItemFetch cur;
+    cur.slot = ITEM_UNUSED;
+    if (v_lo < v_hi) cur = fetch_item(d, v_lo, lane, n);
+    for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
+    for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
+    __syncthreads();
     const uint32_t route_base = d.n_bld + d.n_room;
     WaveScratch &ws = wsc[threadIdx.x >> 6];
+    const uint32_t pt1 = PROF_NOW();
     // (1) buildings and school rooms: one wavefront per item
-    for (uint32_t v = wave; v < n_items; v += n_waves) {
-        if (d.hitems[v] == ITEM_UNUSED) continue;
-        const ItemRec rec = d.item_rec[v];
-        if (rec.id >= route_base) continue;
-        if (rec.id < d.n_bld) {
-            if (rec.aux == ESIM_SCHOOL) continue;                             // School::find_exposures works per room
-            const uint32_t S = item_steps(d, v, lane, n, ws);
+    for (uint32_t v = v_lo; v < v_hi; ++v) {
+        const ItemFetch it = cur;
+        if (it.slot == ITEM_UNUSED) break;
+        if (v + 1u < v_hi) cur = fetch_item(d, v + 1u, lane, n);
+        if (it.id >= route_base) continue;
+        const uint32_t pi0 = PROF_NOW();
+        (void)pi0; ++p_items;
+        if (it.id < d.n_bld) {
+            if (it.aux == ESIM_SCHOOL) continue;                              // School::find_exposures works per room
+            // first 64 residents and workers and their words: both lists' loads are in flight together
+            const uint32_t n_res = it.a_hi - it.a_lo, n_wrk = it.b_hi - it.b_lo;
+            uint32_t rm = 0u, wm = 0u, rw = 0u, ww = 0u;
+            if (lane < n_res) rm = d.res_idx ? d.res_idx[it.a_lo + lane] : it.a_lo + lane;
+            if (lane < n_wrk) wm = d.wrk_idx[it.b_lo + lane];
+            if (lane < n_res) rw = d.cit[rm];
+            if (lane < n_wrk) ww = d.cit[wm];
+            const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws);
             __builtin_amdgcn_wave_barrier();
             // Household / Workplace::find_exposures: every registered occupant (building.rs:202-204,278-280)
-            list_or_units(d, ctrl, sm, ws, d.res_idx, rec.a_lo, rec.a_hi, v, lane, 0u, S, t0);
-            list_or_units(d, ctrl, sm, ws, d.wrk_idx, rec.b_lo, rec.b_hi, v, lane, 1u, S, t0);
+            list_or_units(d, ctrl, sm, ws, d.res_idx, it.a_lo, it.a_hi, v, lane, 0u, S, t0, true, rm, rw);
+            list_or_units(d, ctrl, sm, ws, d.wrk_idx, it.b_lo, it.b_hi, v, lane, 1u, S, t0, true, wm, ww);
         } else {
-            const uint32_t S = item_steps(d, v, lane, n, ws);
-            school_counts(d, rec.aux, lane, n, ws);
+            const uint32_t n_mem = it.a_hi - it.a_lo;
+            uint32_t mm = 0u, mw = 0u;
+            if (lane < n_mem) mm = d.room_idx[it.a_lo + lane];
+            school_counts(d, it.link, lane, n, ws);
+            if (lane < n_mem) mw = d.cit[mm];
+            const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws);
             __builtin_amdgcn_wave_barrier();
             // School::find_exposures: the room once per infected in it (building.rs:494-522)
-            list_or_units(d, ctrl, sm, ws, d.room_idx, rec.a_lo, rec.a_hi, v, lane, 2u, S, t0);
+            list_or_units(d, ctrl, sm, ws, d.room_idx, it.a_lo, it.a_hi, v, lane, 2u, S, t0, true, mm, mw);
         }
         __builtin_amdgcn_wave_barrier();
+        { const uint32_t dt = PROF_NOW() - pi0; p_item_max = dt > p_item_max ? dt : p_item_max; }
     }
+    const uint32_t pt2 = PROF_NOW();
     // (2) routes of <= 64 riders: one wavefront per (route, bus step) with an Infected rider; rank by (Philox key, id)
     // with shuffles, buses are runs of bus_capacity ranks (simulator.rs:362-388)
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
-    const uint32_t n_small = min(ld(&ctrl->n_route_pairs), d.items_cap);
-    for (uint32_t q = wave; q < n_small; q += n_waves) {
-        const uint32_t code = d.route_pairs[q], v = code >> 7, j = code & 127u;
-        const uint32_t r = d.item_rec[v].id - route_base;
-        const uint32_t off = d.route_off[r], sz = d.route_off[r + 1] - off;
+    // Wavefront w of k_chunk_marks left pair_cnt[w] pairs in its own stretch of the list.  They are dealt out so that the
+    // k-th pair of w goes to wavefront (w + k * PAIR_SPREAD) mod n_waves: here lane k looks at the stretch it may have
+    // been dealt from, and the wavefront then takes the pairs that exist one by one.
+    const uint32_t K = 2u * per_wave;                                          // pairs a stretch can hold
+    for (uint32_t k0 = 0; k0 < K; k0 += 64u) {
+        const uint32_t kk = k0 + lane;
+        uint32_t code_l = 0u, off_l = 0u, sz_l = 0u;
+        bool have = false;
+        if (kk < K) {
+            const uint32_t src = (wave + n_waves - (uint32_t)(((unsigned long long)kk * PAIR_SPREAD) % n_waves)) % n_waves;
+            have = kk < d.pair_cnt[src];
+            code_l = d.route_pairs[(size_t)src * K + kk];                      // in bounds whether or not the pair exists
+        }
+        if (have) { const uint32_t r = code_l >> 7; off_l = d.route_off[r]; sz_l = d.route_off[r + 1] - off_l; }
+        unsigned long long todo = __ballot(have);
+        while (todo) {
+        const int src_lane = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const uint32_t code = __shfl(code_l, src_lane, 64), off = __shfl(off_l, src_lane, 64), sz = __shfl(sz_l, src_lane, 64);
+        const uint32_t j = code & 127u;
         const uint32_t s = t0 + j, mask = sm.dec[j].mask;
         uint32_t c = 0, w = 0, key = 0;
         bool inf = false;
@@ -976,15 +1122,17 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
         }
         uint32_t rank = 0;
         for (uint32_t i = 0; i < sz; ++i) {
-            const uint32_t ki = __shfl(key, (int)i, 64);
+            const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)i);   // i is uniform: a scalar broadcast
             rank += ki < key || (ki == key && i < lane);                     // ids ascend with the lane
         }
         const uint32_t bus = rank / d.bus_capacity;
+        // Infected riders on my bus: one ballot per bus of the route
+        const unsigned long long inf_m = __ballot(inf);
         uint32_t k = 0;
-        for (uint32_t i = 0; i < sz; ++i) {
-            const uint32_t bi = __shfl(bus, (int)i, 64);
-            const bool ii = __shfl((int)inf, (int)i, 64);
-            k += ii && bi == bus;
+        const uint32_t n_bus = (sz + d.bus_capacity - 1u) / d.bus_capacity;
+        for (uint32_t b = 0; b < n_bus; ++b) {
+            const unsigned long long on_b = __ballot(lane < sz && bus == b);
+            if (bus == b) k = (uint32_t)__popcll(on_b & inf_m);
         }
         if (lane < sz && k) {
             const uint32_t te = CW_TE(w);
@@ -993,14 +1141,33 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
                 if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
             }
         }
+        }
     }
-    // (3) longer routes: one workgroup per (route, bus step), ranks through LDS
-    const uint32_t n_pairs = min(ld(&ctrl->n_route_pairs_big), d.items_cap);
+    const uint32_t pt3 = PROF_NOW();
+    PROF_PUT(d, 0, pt0); PROF_PUT(d, 1, pt1); PROF_PUT(d, 2, pt2); PROF_PUT(d, 3, pt3);   // start, after preamble, after items, end
+    PROF_PUT(d, 4, p_items); PROF_PUT(d, 5, p_item_max);
+}
+
+// Routes of more than 64 riders: one workgroup per (route, bus step), ranks through LDS.  Launched only for
+// populations that have such a route.
+__global__ __launch_bounds__(TPB) void k_chunk_routes_big(Dev d)
+{
+    __shared__ RouteShared sm;
+    __shared__ Decision s_dec[FREE_MAX];
+    __shared__ uint64_t s_thr[512];
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t t0 = ctrl->chunk_t0, n = ctrl->chunk_ok;
+    if (!ctrl->chunk_parallel || n == 0u) return;
+    const uint32_t n_pairs = min(ld(&d.hot[HOT_BIGPAIRS * HOT_STRIDE]), 2u * d.items_cap);
+    if (n_pairs == 0u) return;
+    for (uint32_t i = threadIdx.x; i < n; i += TPB) s_dec[i] = d.dec[i];
+    for (uint32_t i = threadIdx.x; i < 512u; i += TPB) s_thr[i] = d.thr[i];
+    __syncthreads();
+    const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
     for (uint32_t q = blockIdx.x; q < n_pairs; q += gridDim.x) {
-        const uint32_t code = d.route_pairs_big[q], v = code >> 7, j = code & 127u;
-        const uint32_t r = d.item_rec[v].id - route_base;
+        const uint32_t code = d.route_pairs_big[q], r = code >> 7, j = code & 127u;
         const uint32_t off = d.route_off[r], sz = d.route_off[r + 1] - off;
-        const uint32_t s = t0 + j, mask = sm.dec[j].mask;
+        const uint32_t s = t0 + j, mask = s_dec[j].mask;
         for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
             const uint32_t c = d.route_riders[off + i];
             sm.s_key[i] = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
@@ -1024,7 +1191,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
             const uint32_t w = d.cit[c], te = CW_TE(w);
             if (w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_FLAGS)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE)) continue;   // exposed before this bus
             const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
-            if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
+            if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < s_thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
         }
         __syncthreads();
     }
@@ -1038,23 +1205,40 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
     Ctrl *ctrl = d.ctrl;
     const uint32_t t0 = ctrl->chunk_t0, n = ctrl->chunk_ok;
     if (!ctrl->chunk_parallel || n == 0u) return;
-    const uint32_t n_units = min(ld(&ctrl->n_units), d.units_cap);
-    if (n_units == 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    // queue `wave & 63`, every (n_waves / 64)-th unit of it
+    const uint32_t qr = wave & (SUBQ - 1u), first = wave / SUBQ, step = n_waves / SUBQ;
+    const uint32_t n_units = step ? min(ld(&d.hot[(HOT_UNITS + qr) * HOT_STRIDE]), d.unit_qcap) : 0u;
+    if (__syncthreads_or(first < n_units) == 0) return;
     for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
     for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
     WaveScratch &ws = wsc[threadIdx.x >> 6];
-    for (uint32_t q = wave; q < n_units; q += n_waves) {
-        const uint32_t code = d.unit_item[q], v = code & 0x3FFFFFFFu, kind = code >> 30, p_lo = d.unit_lo[q];
-        const ItemRec rec = d.item_rec[v];
-        const uint32_t S = item_steps(d, v, lane, n, ws);
+    const uint32_t *q_item = d.unit_item + (size_t)qr * d.unit_qcap, *q_lo = d.unit_lo + (size_t)qr * d.unit_qcap;
+    // three units in flight per wavefront: (item, first pair) of the one after next, the item record and counts of the
+    // next, the draws of this one
+    uint32_t code_a = UNIT_NOOP, plo_a = 0u, code_b = UNIT_NOOP, plo_b = 0u;
+    ItemFetch it_b;
+    it_b.slot = ITEM_UNUSED;
+    if (first < n_units) { code_b = q_item[first]; plo_b = q_lo[first]; }
+    if (first + step < n_units) { code_a = q_item[first + step]; plo_a = q_lo[first + step]; }
+    if (code_b != UNIT_NOOP) it_b = fetch_item(d, code_b & 0x3FFFFFFFu, lane, n);
+    for (uint32_t q = first; q < n_units; q += step) {
+        const uint32_t code = code_b, p_lo = plo_b;
+        const ItemFetch it = it_b;
+        code_b = code_a; plo_b = plo_a;
+        if (q + step < n_units && code_b != UNIT_NOOP) it_b = fetch_item(d, code_b & 0x3FFFFFFFu, lane, n);
+        code_a = UNIT_NOOP;
+        if (q + 2u * step < n_units) { code_a = q_item[q + 2u * step]; plo_a = q_lo[q + 2u * step]; }
+        if (code == UNIT_NOOP) continue;
+        const uint32_t kind = code >> 30;
         uint32_t lo, hi;
         const uint32_t *idx;
-        if (kind == 2u) { lo = rec.a_lo; hi = rec.a_hi; idx = d.room_idx; school_counts(d, rec.aux, lane, n, ws); }
-        else if (kind == 1u) { lo = rec.b_lo; hi = rec.b_hi; idx = d.wrk_idx; }
-        else { lo = rec.a_lo; hi = rec.a_hi; idx = d.res_idx; }
+        if (kind == 2u) { lo = it.a_lo; hi = it.a_hi; idx = d.room_idx; school_counts(d, it.link, lane, n, ws); }
+        else if (kind == 1u) { lo = it.b_lo; hi = it.b_hi; idx = d.wrk_idx; }
+        else { lo = it.a_lo; hi = it.a_hi; idx = d.res_idx; }
+        const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws);
         __builtin_amdgcn_wave_barrier();
         const uint32_t pairs = (hi - lo) * S;
         member_pairs(d, ctrl, sm, ws, idx, lo, p_lo, min(pairs, p_lo + UNIT_PAIRS), lane, kind, S, t0);
@@ -1066,9 +1250,12 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
 __global__ __launch_bounds__(TPB) void k_chunk_count(Dev d)
 {
     if (!d.ctrl->chunk_parallel || d.ctrl->chunk_ok == 0u) return;
-    const uint32_t n_new = ld(&d.ctrl->n_newexp);
-    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_new; i += gridDim.x * TPB) {
-        const uint32_t w = d.cit[d.newexp[i]];
+    // sub-list `thread & 63`, every (threads / 64)-th entry of it
+    const uint32_t tid = blockIdx.x * TPB + threadIdx.x, r = tid & (SUBQ - 1u), step = (gridDim.x * TPB) / SUBQ;
+    const uint32_t n_new = min(ld(&d.hot[(HOT_NEWEXP + r) * HOT_STRIDE]), d.newexp_cap);
+    const uint32_t *list = d.newexp + (size_t)r * d.newexp_cap;
+    for (uint32_t i = tid / SUBQ; i < n_new; i += step) {
+        const uint32_t w = d.cit[list[i]];
         const uint32_t s = CW_TE(w) - TE_BIAS;
         atomicAdd(&d.exp_step[2u * s + ((w & CW_BUS_EXPOSED) ? 1u : 0u)], 1u);
     }
@@ -1081,16 +1268,26 @@ __global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d)
     Ctrl *ctrl = d.ctrl;
     if (!ctrl->chunk_parallel || ctrl->chunk_done == 0u) return;
     const uint32_t t0 = ctrl->chunk_t0;
-    const uint32_t n_new = ld(&ctrl->n_newexp), n_items = min(ld(&ctrl->n_items), d.items_cap);
-    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_new; i += gridDim.x * TPB) {
-        const uint32_t m = d.newexp[i];
-        const uint32_t te = CW_TE(d.cit[m]);
-        d.log[d.log_off[te] + atomicAdd(&d.cursor[te - TE_BIAS - t0], 1u)] = m;
+    const uint32_t n_items = min(ld(&ctrl->n_items), d.items_cap);
+    {
+        const uint32_t tid = blockIdx.x * TPB + threadIdx.x, r = tid & (SUBQ - 1u), step = (gridDim.x * TPB) / SUBQ;
+        const uint32_t n_new = min(ld(&d.hot[(HOT_NEWEXP + r) * HOT_STRIDE]), d.newexp_cap);
+        const uint32_t *list = d.newexp + (size_t)r * d.newexp_cap;
+        for (uint32_t i = tid / SUBQ; i < n_new; i += step) {
+            const uint32_t m = list[i];
+            const uint32_t te = CW_TE(d.cit[m]);
+            d.log[d.log_off[te] + atomicAdd(&d.cursor[te - TE_BIAS - t0], 1u)] = m;
+        }
     }
-    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_items * FREE_MAX; i += gridDim.x * TPB) d.vec[i] = 0u;
-    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_items; i += gridDim.x * TPB) {
-        const uint32_t h = d.hitems[i];
-        if (h != ITEM_UNUSED) { d.hkey[h] = HKEY_EMPTY; d.hval[h] = HVAL_PENDING; }
+    // a wavefront per item id: the count vectors and hash slots of the ids that were handed out
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    for (uint32_t v = wave; v < n_items; v += n_waves) {
+        const uint32_t h = d.hitems[v];
+        if (h == ITEM_UNUSED) continue;
+        d.vec[(size_t)v * FREE_MAX + lane] = 0u;
+        if (lane < FREE_MAX - 64u) d.vec[(size_t)v * FREE_MAX + 64u + lane] = 0u;
+        if (lane == 0) { d.hkey[h] = HKEY_EMPTY; d.hval[h] = HVAL_PENDING; }
     }
 }
 
@@ -1177,6 +1374,12 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_finish(Dev d)
     if (!ctrl->chunk_parallel || ctrl->chunk_ok == 0u) { if (threadIdx.x == 0) ctrl->chunk_done = 0u; return; }
     batch_finish_body(d, ctrl->chunk_t0, ctrl->chunk_ok);
     if (threadIdx.x == 0) ctrl->chunk_done = 1u;
+    if (threadIdx.x < 64u) {
+        // totals of the split lists, for esim_debug_counters
+        uint32_t a = ld(&d.hot[(HOT_NEWEXP + threadIdx.x) * HOT_STRIDE]), b = ld(&d.hot[(HOT_UNITS + threadIdx.x) * HOT_STRIDE]);
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if (threadIdx.x == 0) { ctrl->n_newexp = a; ctrl->n_units = b; ctrl->n_route_pairs_big = ld(&d.hot[HOT_BIGPAIRS * HOT_STRIDE]); }
+    }
 }
 
 // Vaccination bookkeeping for one citizen set to Vaccinated (simulator.rs:551).

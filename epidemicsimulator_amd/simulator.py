@@ -37,6 +37,15 @@ class StatisticsRecorder:
             self.timer_entries.append(timings)
         self.memory_usage_entries.append(_memory_usage())
 
+    def push_block(self, arr):
+        """The same for a block of records (structured array of esim_step_result) that came back from one
+        device-resident run: no per-step Python work beyond list building."""
+        cols = [arr[k].tolist() for k in ("time_step", "susceptible", "exposed", "infected", "recovered", "vaccinated")]
+        keys = ("time_step", "susceptible", "exposed", "infected", "recovered", "vaccinated")
+        self.global_stats.extend(dict(zip(keys, row)) for row in zip(*cols))
+        self.exposures_all.extend((arr["exposures_building"].astype(np.int64) + arr["exposures_bus"]).tolist())
+        self.memory_usage_entries.extend([_memory_usage()] * len(arr))
+
     def dump_to_file(self, directory):
         """statistics.rs:113-150. `dump_to_file` calls next() first, which appends one all-zero
         trailing StatisticEntry (Q14) -- reproduced so downstream notebooks see the same shape."""
@@ -105,16 +114,46 @@ class Simulator:
         return bool(rec["disease_exists"])
 
     def simulate(self, output_name):
+        """simulator.rs:108-127: steps until the disease is gone or max_time_step, a progress line after the steps
+        with index 0, 50, 100, ... and the statistics dump.  With record_timings the loop is the reference's step by
+        step; otherwise the steps between two progress lines are one device-resident run (esim_run with
+        stop_when_done), which produces the same records without a host round trip per step."""
         start = time.time()
         max_time_step = int(self.params.max_steps)
-        for time_step in range(max_time_step):
-            if not self.step():
-                break
-            if time_step % DEBUG_ITERATION_PRINT == 0:
-                print("Completed %3d time steps, in: %6s seconds  Statistics: %s,   Memory usage: %s" % (
-                    DEBUG_ITERATION_PRINT, "%.2f" % (time.time() - start), self.last, _memory_usage()))
-                start = time.time()
+        if self.record_timings:
+            for time_step in range(max_time_step):
+                if not self.step():
+                    break
+                if time_step % DEBUG_ITERATION_PRINT == 0:
+                    self._progress(start)
+                    start = time.time()
+        else:
+            done = 0
+            while done < max_time_step:
+                # the next progress line follows the step with index done' = 0 (mod 50)
+                n = 1 if done == 0 else min(DEBUG_ITERATION_PRINT, max_time_step - done)
+                t_block = time.time()
+                arr = self.run(n, stop_when_done=True)
+                if len(arr) == 0:
+                    break
+                # the phases of simulator.rs:137-143 do not exist separately in a device-resident run: only the
+                # total is known, as the block's wall time spread over its steps
+                per_step = (time.time() - t_block) / len(arr)
+                self.statistics_recorder.timer_entries.extend(
+                    {"Generate Exposures": None, "Apply Exposures": None, "Apply Interventions": None, "total": per_step}
+                    for _ in range(len(arr)))
+                done += len(arr)
+                self.last = {k: int(arr[k][-1]) for k in arr.dtype.names}
+                if not self.last["disease_exists"]:
+                    break
+                if (done - 1) % DEBUG_ITERATION_PRINT == 0:
+                    self._progress(start)
+                    start = time.time()
         self.statistics_recorder.dump_to_file(output_name)
+
+    def _progress(self, start):
+        print("Completed %3d time steps, in: %6s seconds  Statistics: %s,   Memory usage: %s" % (
+            DEBUG_ITERATION_PRINT, "%.2f" % (time.time() - start), self.last, _memory_usage()))
 
     # -- device-resident loop ----------------------------------------------------------
     def run(self, n_steps, stop_when_done=False):
@@ -125,8 +164,7 @@ class Simulator:
         _lib.check(self.lib.esim_run(self._ctx, n_steps, int(stop_when_done), buf, C.byref(n_done)), self._ctx)
         self._steps += n_done.value
         arr = np.frombuffer(buf, dtype=RECORD_DTYPE, count=n_done.value).copy()
-        for i in range(n_done.value):
-            self.statistics_recorder.push({k: int(arr[k][i]) for k in arr.dtype.names})
+        self.statistics_recorder.push_block(arr)
         return arr
 
     def reset(self):

@@ -216,6 +216,39 @@ def test_simulate_writes_the_reference_output_files(tmp_path):
     sim.close()
 
 
+def test_simulate_device_resident_blocks(tmp_path, capsys):
+    # without per-step timers simulate() runs the steps between two progress lines on the device in one go; same
+    # records, same files, same number of progress lines (after the steps with index 0, 50, 100)
+    import json
+    pop = Population.synthetic("york", n_citizens=3000, n_areas=10, citizens_per_school=1500, n_seeds=8)
+    ep = _lib.default_params(max_steps=130, **{k: v for k, v in AGGRESSIVE.items()})
+    sim = Simulator(pop, ep)
+    out = str(tmp_path) + "/run/"
+    sim.simulate(out)
+    assert capsys.readouterr().out.count("Completed  50 time steps") == 3
+    stats = json.load(open(out + "global_stats.json"))
+    orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep)).run(130)
+    assert len(stats) == 131
+    for f in ("susceptible", "exposed", "infected", "recovered", "vaccinated"):
+        assert [e[f] for e in stats[:-1]] == [int(x) for x in orc[f]]
+    assert [e["time_step"] for e in stats] == list(range(1, 132))
+    timings = json.load(open(out + "timings.json"))
+    assert len(timings) == 130 and all(t["total"] > 0 for t in timings)
+    assert len(json.load(open(out + "memory.json"))) == 130
+    sim.close()
+    # an epidemic that dies out stops the loop at the same step as the reference's `if !self.step() { break }`
+    n = 64
+    home = np.arange(n, dtype=np.uint32) // 4
+    pop1 = Population(home_building=home, work_building=home.copy(), flags=np.zeros(n, np.uint8),
+                      building_area=np.zeros(n // 4, np.uint32), building_type=np.zeros(n // 4, np.uint8),
+                      seeds=np.arange(n, dtype=np.uint32), n_areas=1)
+    sim1 = Simulator(pop1, _lib.default_params(vaccination_threshold=2.0, max_steps=2000))
+    sim1.simulate(str(tmp_path) + "/gone/")
+    gone = json.load(open(str(tmp_path) + "/gone/global_stats.json"))
+    assert len(gone) == 337 + 1 and gone[336]["recovered"] == n
+    sim1.close()
+
+
 def random_population(seed, n=700, n_areas=5, n_buildings=90, n_schools=3, rooms_per_school=4):
     """Anything the ABI allows, not just what the reference's builder produces: workplaces in other areas,
     people working in somebody's household, tiny and empty buildings, rooms with one member, citizens that
