@@ -330,10 +330,12 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         d.hcap = cap;
         d.items_cap = cap / 4u;                     // load factor <= 1/4; one count vector of FREE_MAX steps per item
         if ((rc = dev_alloc(c, &d.hkey, cap))) return rc;
-        if ((rc = dev_alloc(c, &d.hval, cap))) return rc;
         if ((rc = dev_alloc(c, &d.hitems, d.items_cap))) return rc;
         if ((rc = dev_alloc(c, &d.item_rec, d.items_cap))) return rc;
-        if ((rc = dev_alloc(c, &d.vec, (size_t)d.items_cap * FREE_MAX))) return rc;
+        if ((rc = dev_alloc(c, &d.vec, (size_t)cap * FREE_MAX))) return rc;
+        if ((rc = dev_alloc(c, &d.slot_state, cap))) return rc;
+        if ((rc = dev_alloc(c, &d.slot_iv, (size_t)cap * 8u))) return rc;
+        HIP_TRY(c, hipMemset(d.slot_state, 0, sizeof(uint32_t) * cap));
         // deferred units: SUBQ queues; a queue that is full makes its producer draw the list itself, so the size is a
         // matter of speed only.  Room for the smaller of: every long member list marked in every step; a quarter of the
         // citizens -- four times over, since the queues fill unevenly.
@@ -355,12 +357,11 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if ((rc = dev_alloc(c, &d.hot, (size_t)HOT_COUNT * HOT_STRIDE))) return rc;
         HIP_TRY(c, hipMemset(d.hot, 0, sizeof(uint32_t) * HOT_COUNT * HOT_STRIDE));
         HIP_TRY(c, hipMemset(d.pair_cnt, 0, sizeof(uint32_t) * 16384u));
-        HIP_TRY(c, hipMemset(d.hval, 0xFF, sizeof(uint32_t) * cap));
         d.newexp_cap = N / SUBQ + 1u;                 // citizens with the same id & 63: nobody is listed twice in a chunk
         if ((rc = dev_alloc(c, &d.newexp, (size_t)d.newexp_cap * SUBQ))) return rc;
         if ((rc = dev_alloc(c, &d.cursor, FREE_MAX))) return rc;
         HIP_TRY(c, hipMemset(d.hkey, 0xFF, sizeof(unsigned long long) * cap));
-        HIP_TRY(c, hipMemset(d.vec, 0, sizeof(uint32_t) * (size_t)d.items_cap * FREE_MAX));
+        HIP_TRY(c, hipMemset(d.vec, 0, sizeof(uint32_t) * (size_t)cap * FREE_MAX));
         HIP_TRY(c, hipMemset(d.cursor, 0, sizeof(uint32_t) * FREE_MAX));
     }
     for (int p = 0; p < (int)MARK_SLOTS; ++p) {

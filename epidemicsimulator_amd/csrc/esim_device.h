@@ -80,7 +80,8 @@ struct Ctrl {
 
 // An item of a time-parallel chunk: a building (a = residents, b = workers, aux = type), a school room (a =
 // participants, aux = its school building) or a route.
-struct ItemRec { uint32_t id, a_lo, a_hi, b_lo, b_hi, aux, link, pad1; };   // link: a room's school item
+struct ItemRec { uint32_t id, a_lo, a_hi, b_lo, b_hi, aux, link, own; };   // link: a room's school item; own: the claimer's interval record
+#define ITEM_RECS 7u               // interval records an item holds besides its claimer's
 
 // What is in force during one step of a pipelined chunk (k_decide fills dec[0..chunk_ok]).
 struct Decision {
@@ -112,11 +113,13 @@ struct Dev {
     struct Decision *dec;       // [FREE_MAX + 1]
     // time-parallel chunks: infected per (building | room | route, step of the chunk) in an open-addressing hash map
     unsigned long long *hkey;   // [hcap] slot id (building | n_bld + room | n_bld + n_room + route), HKEY_EMPTY when free
-    uint32_t *hval;             // [hcap] item index of the key
     uint32_t hcap;              // power of two
     uint32_t *hitems;           // [items_cap] hash slot of each item of the chunk (ITEM_UNUSED: id not handed out)
     struct ItemRec *item_rec;   // [items_cap] what the draw pass needs of an item, written at claim time
-    uint32_t *vec;              // [items_cap][FREE_MAX] infected standing in the item in each step of the chunk
+    uint32_t *slot_state;       // [hcap] buildings, rooms: interval records asked for (beyond ITEM_RECS they went into `vec`);
+                                // routes: bit i = the i-th bus step of the chunk has been registered
+    uint32_t *slot_iv;          // [hcap][8] interval records (k_chunk_marks: IV_*)
+    uint32_t *vec;              // [hcap][FREE_MAX] per-step counts of the Infected that found no record free
     uint32_t items_cap;
     uint32_t *unit_item, *unit_lo;  // [SUBQ][unit_qcap] item | kind << 30 (UNIT_NOOP: skip), first pair of the unit
     uint32_t *route_pairs;      // [2 * items_cap] route << 7 | step of the chunk, routes of <= 64 riders: wavefront w of

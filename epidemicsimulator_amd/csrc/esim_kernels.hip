@@ -712,14 +712,11 @@ __device__ __forceinline__ uint32_t hash64(unsigned long long k)
     return (uint32_t)k;
 }
 
-// Items live in an open-addressing hash map keyed by slot id (building | n_bld + room | n_bld + n_room + route).
-// Claiming is two-phase so that a wavefront has published ALL its own claims before any of its lanes waits:
-// item_probe never waits; the claiming lanes then take indices from their wavefront's own id range (a counter
-// bumped once per claim would serialise the pass) and publish them; item_wait is
-// called after the lanes have reconverged by those that found the key already there, and waits (bounded) for the
-// index.  The claimer it waits for sits in a wavefront that is still probing or already past its claims -- never
-// itself waiting with an unpublished claim.
-#define HVAL_PENDING 0xFFFFFFFFu
+// Items live in an open-addressing hash map keyed by (building | n_bld + room | n_bld + n_room + route).  Whoever
+// inserts the key claims the item: it takes the next id of its wavefront's own id range (a counter bumped once per claim
+// would serialise the pass) and writes the item's record.  Everything the others add to the item -- their interval
+// records, the per-step counters of those that found no record free, a route's registered bus steps -- is indexed by the
+// hash SLOT, which the probe itself returns: nobody ever waits for anybody.
 #define ITEM_UNUSED 0xFFFFFFFFu
 __device__ __forceinline__ bool item_probe(const Dev &d, Ctrl *ctrl, unsigned long long key, uint32_t &slot, bool &pending)
 {
@@ -736,28 +733,18 @@ __device__ __forceinline__ bool item_probe(const Dev &d, Ctrl *ctrl, unsigned lo
     return false;
 }
 
-__device__ __forceinline__ uint32_t item_wait(const Dev &d, Ctrl *ctrl, uint32_t slot)
+// An interval record: a citizen that is Infected in steps [a, b] of the chunk, the flags that decide where it stands
+// in each of them, and whether the record sits in its work building / room or in its home.
+#define IV_VALID   0x80000000u
+#define IV_PT      (1u << 14)
+#define IV_HW      (1u << 15)
+#define IV_AS_WORK (1u << 16)
+__device__ __forceinline__ uint32_t iv_present(uint32_t iv, uint32_t j, const Decision &q)
 {
-    for (uint32_t spin = 0; spin < (1u << 20); ++spin) {
-        const uint32_t v = __hip_atomic_load(&d.hval[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v != HVAL_PENDING) return v;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    ctrl->error = (uint32_t)(-ESIM_ERANGE);
-    return 0u;
-}
-
-// Item index of `key` once every claim of the chunk is done, 0xFFFFFFFF when it has no item.
-__device__ __forceinline__ uint32_t item_find(const Dev &d, unsigned long long key)
-{
-    uint32_t h = hash64(key) & (d.hcap - 1u);
-    for (uint32_t probe = 0; probe < d.hcap; ++probe) {
-        const unsigned long long k = d.hkey[h];
-        if (k == key) return d.hval[h];
-        if (k == HKEY_EMPTY) return 0xFFFFFFFFu;
-        h = (h + 1u) & (d.hcap - 1u);
-    }
-    return 0xFFFFFFFFu;
+    if (!(iv & IV_VALID) || j < (iv & 127u) || j > ((iv >> 7) & 127u)) return 0u;
+    if (q.bus_dir && (iv & IV_PT)) return 0u;                                 // on a bus (simulator.rs:181-186)
+    const bool at_work = q.at_work && (iv & IV_HW);
+    return ((iv & IV_AS_WORK) != 0u) == at_work ? 1u : 0u;
 }
 
 // Where an Infected citizen stands in step s of the chunk (simulator.rs:181-198): bit 0 in the home building,
@@ -800,6 +787,11 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
     uint32_t next_id = wave * per_wave;
     const Decision q0 = lane < n ? d.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
     const Decision q1 = 64u + lane < n ? d.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
+    // The steps of the chunk in which riders are on a bus, in order (at most CHUNK_BUS_STEPS, k_decide): a route item keeps
+    // one bit per such step -- "an Infected rider of this route has registered the (route, step) pair".
+    const unsigned long long busm0 = __ballot(lane < n && q0.bus_dir != 0u), busm1 = __ballot(64u + lane < n && q1.bus_dir != 0u);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t bidx0 = (uint32_t)__popcll(busm0 & lt), bidx1 = (uint32_t)(__popcll(busm0) + __popcll(busm1 & lt));   // index of my step among them
     // lanes 0..3 own one key each: home building, work building, room, route.  The entry after this one is fetched
     // (log entry, word, the lane's key source) before the work on this one: the hash claim's round trips overlap it.
     const uint32_t *key_src = lane == 0 ? d.home : lane == 1 ? d.work : lane == 2 ? d.room : d.route_of;
@@ -808,8 +800,11 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
     uint32_t my_pairs = 0u;                                                   // (route, bus step) pairs this wavefront registered
     uint32_t c_n = 0u, w_n = 0u, k_n = 0u;
     if (i0 + wave < i1) { c_n = d.log[i0 + wave]; w_n = d.cit[c_n]; if (lane < 4u) k_n = key_src[c_n]; }
+    uint32_t ps[5] = { 0u, 0u, 0u, 0u, 0u };                                   // diagnostics: time per stage
+    const uint32_t pm_loop = PROF_NOW();
     for (uint32_t e = i0 + wave; e < i1; e += n_waves) {
         const uint32_t w = w_n, ksrc = k_n;
+        const uint32_t pa = PROF_NOW();
         if (e + n_waves < i1) { c_n = d.log[e + n_waves]; w_n = d.cit[c_n]; if (lane < 4u) k_n = key_src[c_n]; }
         const uint32_t p0 = lane < n ? where_in_step(d, w, t0 + lane, q0) : 0u;
         const uint32_t p1 = 64u + lane < n ? where_in_step(d, w, t0 + 64u + lane, q1) : 0u;
@@ -817,43 +812,76 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         const bool school = w & FL_WORK_SCHOOL;
         if (!any_home && !any_work && !any_bus) continue;
         ++p_entries;
+        const uint32_t pb = PROF_NOW();
+        // the citizen is Infected in steps [a, b] of the chunk (one stretch: disease.rs:60-65); where it stands in each of
+        // them follows from the record's flags and the step's schedule (iv_present)
+        const int a_abs = (int)CW_TE(w) - (int)TE_BIAS + (int)d.exposed_time + 1;
+        const uint32_t iv_a = a_abs > (int)t0 ? (uint32_t)(a_abs - (int)t0) : 0u;
+        const uint32_t iv_b = min((uint32_t)(a_abs + (int)d.infected_time - (int)t0), n - 1u);
+        const uint32_t iv = IV_VALID | iv_a | (iv_b << 7) | ((w & FL_USES_PT) ? IV_PT : 0u) | ((w & FL_HAS_WORK) ? IV_HW : 0u) |
+                            ((lane == 1u || lane == 2u) ? IV_AS_WORK : 0u);
         unsigned long long key = HKEY_EMPTY;
         if (lane == 0 && any_home) key = ksrc;
         if (lane == 1 && any_work) key = ksrc;
         if (lane == 2 && any_work && school) key = (unsigned long long)d.n_bld + ksrc;
         if (lane == 3 && any_bus) key = (unsigned long long)d.n_bld + d.n_room + ksrc;
-        uint32_t v = 0xFFFFFFFFu, slot = 0u;
+        uint32_t slot = 0u;
         bool pending = false, claimed = false;
         if (key != HKEY_EMPTY) claimed = item_probe(d, ctrl, key, slot, pending);
         const unsigned long long cm = __ballot(claimed);
+        const uint32_t pc = PROF_NOW();
+        const uint32_t s_home = __shfl(slot, 0, 64), s_work = __shfl(slot, 1, 64), s_room = __shfl(slot, 2, 64);
         if (claimed) {
-            v = next_id + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
+            const uint32_t v = next_id + (uint32_t)__popcll(cm & lt);
             d.hitems[v] = slot;
-            __hip_atomic_store(&d.hval[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // claims are published here ...
-            // what the draw pass needs of the item (read by later kernels only)
+            // what the draw pass needs of the item; the claimer's own stretch travels in it, and a room's record names the
+            // slot of its school (the citizen's work building, lane 1)
             const uint32_t id = (uint32_t)key;
-            ItemRec rec = { id, 0u, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u };
+            // (a school's counts are looked up by slot from its rooms, so even its claimer's stretch goes into a slot record)
+            ItemRec rec = { id, 0u, 0u, 0u, 0u, 0u, lane == 2u ? s_work : 0xFFFFFFFFu, (lane < 3u && !(lane == 1u && school)) ? iv : 0u };
             if (id < d.n_bld) { rec.a_lo = d.res_off[id]; rec.a_hi = d.res_off[id + 1]; rec.b_lo = d.wrk_off[id]; rec.b_hi = d.wrk_off[id + 1]; rec.aux = d.bld_type[id]; }
             else if (id < d.n_bld + d.n_room) { const uint32_t r = id - d.n_bld; rec.a_lo = d.room_off[r]; rec.a_hi = d.room_off[r + 1]; rec.aux = d.room_bld[r]; }
             d.item_rec[v] = rec;
         }
         next_id += (uint32_t)__popcll(cm);
-        __builtin_amdgcn_wave_barrier();
-        if (pending) v = item_wait(d, ctrl, slot);                            // ... before any lane waits for somebody else's
-        const uint32_t v_home = __shfl(v, 0, 64), v_work = __shfl(v, 1, 64), v_room = __shfl(v, 2, 64), v_bus = __shfl(v, 3, 64);
-        if (lane == 2 && claimed) d.item_rec[v].link = v_work;                // a room's record points at its school's item
-        if (p0 & 1u) atomicAdd(&d.vec[(size_t)v_home * FREE_MAX + lane], 1u);
-        if (p1 & 1u) atomicAdd(&d.vec[(size_t)v_home * FREE_MAX + 64u + lane], 1u);
-        if (p0 & 2u) { atomicAdd(&d.vec[(size_t)v_work * FREE_MAX + lane], 1u); if (school) atomicAdd(&d.vec[(size_t)v_room * FREE_MAX + lane], 1u); }
-        if (p1 & 2u) { atomicAdd(&d.vec[(size_t)v_work * FREE_MAX + 64u + lane], 1u); if (school) atomicAdd(&d.vec[(size_t)v_room * FREE_MAX + 64u + lane], 1u); }
-        // the first Infected rider of a (route, step) registers the pair: each gets a workgroup of its own in k_chunk_draw
+        const uint32_t pd = PROF_NOW();
+        // somebody else's building / room: my stretch goes into one of the slot's ITEM_RECS records; when they are taken,
+        // into its per-step counters (`vec`), one atomic per step
+        bool spill = false;
+        if (lane < 3u && (pending || (claimed && lane == 1u && school))) {
+            const uint32_t pos = atomicAdd(&d.slot_state[slot], 1u);
+            if (pos < ITEM_RECS) d.slot_iv[(size_t)slot * 8u + pos] = iv; else spill = true;
+        }
+        // the route: which of my bus steps nobody has registered yet
+        uint32_t new_bits = 0u;
         if (any_bus) {
-            const bool f0 = (p0 & 4u) && atomicAdd(&d.vec[(size_t)v_bus * FREE_MAX + lane], 1u) == 0u;
-            const bool f1 = (p1 & 4u) && atomicAdd(&d.vec[(size_t)v_bus * FREE_MAX + 64u + lane], 1u) == 0u;
+            const unsigned long long r0 = __ballot((p0 & 4u) != 0u), r1 = __ballot((p1 & 4u) != 0u);
+            uint32_t mine = 0u;                                               // bit i: I ride, Infected, in the i-th bus step of the chunk
+            for (unsigned long long m = busm0 & r0; m; m &= m - 1ull) mine |= 1u << __popcll(busm0 & ((m & (0ull - m)) - 1ull));
+            for (unsigned long long m = busm1 & r1; m; m &= m - 1ull) mine |= 1u << (__popcll(busm0) + __popcll(busm1 & ((m & (0ull - m)) - 1ull)));
+            if (lane == 3u) new_bits = mine & ~atomicOr(&d.slot_state[slot], mine);
+            new_bits = __shfl(new_bits, 3, 64);
+        }
+        const bool sp_home = __shfl((int)spill, 0, 64), sp_work = __shfl((int)spill, 1, 64), sp_room = __shfl((int)spill, 2, 64);
+        const uint32_t pe = PROF_NOW();
+        if (sp_home) {
+            if (p0 & 1u) atomicAdd(&d.vec[(size_t)s_home * FREE_MAX + lane], 1u);
+            if (p1 & 1u) atomicAdd(&d.vec[(size_t)s_home * FREE_MAX + 64u + lane], 1u);
+        }
+        if (sp_work) {
+            if (p0 & 2u) atomicAdd(&d.vec[(size_t)s_work * FREE_MAX + lane], 1u);
+            if (p1 & 2u) atomicAdd(&d.vec[(size_t)s_work * FREE_MAX + 64u + lane], 1u);
+        }
+        if (sp_room) {
+            if (p0 & 2u) atomicAdd(&d.vec[(size_t)s_room * FREE_MAX + lane], 1u);
+            if (p1 & 2u) atomicAdd(&d.vec[(size_t)s_room * FREE_MAX + 64u + lane], 1u);
+        }
+        if (new_bits) {
+            // register the (route, step) pairs that are new: k_chunk_draw ranks the riders of each once
+            const bool f0 = (p0 & 4u) && ((new_bits >> bidx0) & 1u), f1 = (p1 & 4u) && ((new_bits >> bidx1) & 1u);
             const uint32_t rt = __shfl(ksrc, 3, 64);                          // the route itself, not its item: saves the pass a hop
             const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
             const uint32_t add = (uint32_t)(__popcll(m0) + __popcll(m1));     // <= CHUNK_BUS_STEPS (k_decide)
-            const unsigned long long lt = (1ull << lane) - 1ull;
             if (!(w & FL_BIG_ROUTE)) {
                 // this wavefront's own stretch of the list: no shared counter
                 uint32_t *list = d.route_pairs + (size_t)wave * 2u * per_wave;
@@ -862,7 +890,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
                     if (f1) list[my_pairs + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1 & lt)] = (rt << 7) | (64u + lane);
                     my_pairs += add;
                 } else if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE);
-            } else if (add) {
+            } else {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(&d.hot[HOT_BIGPAIRS * HOT_STRIDE], add);
                 base = __shfl(base, 0, 64);
@@ -872,10 +900,13 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
                 } else if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE);
             }
         }
+        { const uint32_t pf = PROF_NOW(); ps[0] += pb - pa; ps[1] += pc - pb; ps[2] += pd - pc; ps[3] += pe - pd; ps[4] += pf - pe; }
     }
     if (lane == 0) d.pair_cnt[wave] = my_pairs;
     const uint32_t pm1 = PROF_NOW();
     PROF_PUT(d, 8, pm0); PROF_PUT(d, 9, pm1); PROF_PUT(d, 10, p_entries);
+    PROF_PUT(d, 11, ps[0]); PROF_PUT(d, 12, ps[1]); PROF_PUT(d, 13, ps[2]); PROF_PUT(d, 14, ps[3]); PROF_PUT(d, 15, ps[4]);
+    PROF_PUT(d, 6, pm_loop - pm0);
 }
 
 // A successful draw of citizen m in step s (bus: on public transport).
@@ -962,24 +993,17 @@ __device__ __forceinline__ uint32_t item_steps_regs(uint32_t c0, uint32_t c1, ui
     return (uint32_t)(__popcll(b0) + __popcll(b1));
 }
 
-__device__ __forceinline__ uint32_t item_steps(const Dev &d, uint32_t v, uint32_t lane, uint32_t n, WaveScratch &ws)
+__device__ __forceinline__ uint32_t fetch_slot(const Dev &d, uint32_t slot, uint32_t lane);
+__device__ __forceinline__ void item_counts(const Dev &d, uint32_t x, uint32_t slot, uint32_t lane, uint32_t n, const Decision &q0,
+                                            const Decision &q1, uint32_t &c0, uint32_t &c1);
+__device__ __forceinline__ void school_counts(const Dev &d, uint32_t s_sch, uint32_t lane, uint32_t n, const Decision &q0, const Decision &q1, WaveScratch &ws)
 {
-    const uint32_t c0 = lane < n ? d.vec[(size_t)v * FREE_MAX + lane] : 0u;
-    const uint32_t c1 = 64u + lane < n ? d.vec[(size_t)v * FREE_MAX + 64u + lane] : 0u;
-    ws.cnt[lane] = c0;
-    if (lane < FREE_MAX - 64u) ws.cnt[64u + lane] = c1;
-    const unsigned long long b0 = __ballot(c0 != 0u), b1 = __ballot(c1 != 0u);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    if (c0) ws.steps[__popcll(b0 & lt)] = (uint8_t)lane;
-    if (c1) ws.steps[__popcll(b0) + __popcll(b1 & lt)] = (uint8_t)(64u + lane);
-    return (uint32_t)(__popcll(b0) + __popcll(b1));
-}
-
-__device__ __forceinline__ void school_counts(const Dev &d, uint32_t v_sch, uint32_t lane, uint32_t n, WaveScratch &ws)
-{
-    // v_sch: the item of the room's school (k_chunk_marks left it in the room's record): infected in the whole school, per step
-    ws.sch[lane] = (v_sch != 0xFFFFFFFFu && lane < n) ? d.vec[(size_t)v_sch * FREE_MAX + lane] : 0u;
-    if (lane < FREE_MAX - 64u) ws.sch[64u + lane] = (v_sch != 0xFFFFFFFFu && 64u + lane < n) ? d.vec[(size_t)v_sch * FREE_MAX + 64u + lane] : 0u;
+    // s_sch: the hash slot of the room's school (k_chunk_marks left it in the room's record): infected in the whole school, per
+    // step.  All of a school's stretches are slot records (k_chunk_marks), so the slot alone gives the count.
+    uint32_t c0 = 0u, c1 = 0u;
+    if (s_sch != 0xFFFFFFFFu) { const uint32_t x = fetch_slot(d, s_sch, lane); item_counts(d, x, s_sch, lane, n, q0, q1, c0, c1); }
+    ws.sch[lane] = c0;
+    if (lane < FREE_MAX - 64u) ws.sch[64u + lane] = c1;
 }
 
 // Lists with more pairs than this are cut into units that any wavefront can take (k_chunk_units), so that one
@@ -1011,15 +1035,61 @@ __device__ __forceinline__ void list_or_units(const Dev &d, Ctrl *ctrl, const Ch
 
 // What a wavefront needs of item v before it can start on it; depends on v alone, so the fetch of the next item is
 // issued before the work on the current one (the pass is bound by chains of dependent loads, not by bandwidth).
+// The fetch of an item is one register in two hops: lanes 0..7 its record and lane 17 its hash slot (ITEM_UNUSED: id not
+// handed out) by item id; then lanes 8..14 the slot's interval records and lane 16 their number by slot.
 struct ItemFetch { uint32_t slot, id, a_lo, a_hi, b_lo, b_hi, aux, link, c0, c1; };
-__device__ __forceinline__ ItemFetch fetch_item(const Dev &d, uint32_t v, uint32_t lane, uint32_t n)
+#define FX(x, i) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (i)))
+__device__ __forceinline__ uint32_t fetch_item(const Dev &d, uint32_t v, uint32_t lane)
+{
+    uint32_t x = 0u;
+    if (lane < 8u) x = reinterpret_cast<const uint32_t *>(d.item_rec)[(size_t)v * 8u + lane];
+    else if (lane == 17u) x = d.hitems[v];
+    return x;
+}
+__device__ __forceinline__ uint32_t fetch_slot(const Dev &d, uint32_t slot, uint32_t lane)
+{
+    uint32_t x = 0u;
+    if (slot != ITEM_UNUSED) {
+        if (lane >= 8u && lane < 8u + ITEM_RECS) x = d.slot_iv[(size_t)slot * 8u + (lane - 8u)];
+        else if (lane == 16u) x = d.slot_state[slot];
+    }
+    return x;
+}
+__device__ __forceinline__ uint32_t merge_fetch(uint32_t by_id, uint32_t by_slot, uint32_t lane)
+{
+    return (lane < 8u || lane == 17u) ? by_id : by_slot;
+}
+
+// Infected standing in the item in step `lane` (c0) and `64 + lane` (c1) of the chunk: the records of its slot, plus the
+// per-step counters of those that found no record free.  (The claimer's own stretch is added by decode_item.)
+__device__ __forceinline__ void item_counts(const Dev &d, uint32_t x, uint32_t slot, uint32_t lane, uint32_t n, const Decision &q0,
+                                            const Decision &q1, uint32_t &c0, uint32_t &c1)
+{
+    const uint32_t state = FX(x, 16);
+    c0 = 0u; c1 = 0u;
+    if (state > ITEM_RECS) {
+        if (lane < n) c0 = d.vec[(size_t)slot * FREE_MAX + lane];
+        if (64u + lane < n) c1 = d.vec[(size_t)slot * FREE_MAX + 64u + lane];
+    }
+    const uint32_t n_rec = state < ITEM_RECS ? state : ITEM_RECS;
+    for (uint32_t k = 0; k < n_rec; ++k) {
+        const uint32_t iv = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)(8u + k));
+        if (lane < n) c0 += iv_present(iv, lane, q0);
+        if (64u + lane < n) c1 += iv_present(iv, 64u + lane, q1);
+    }
+}
+
+__device__ __forceinline__ ItemFetch decode_item(const Dev &d, uint32_t x, uint32_t lane, uint32_t n, const Decision &q0, const Decision &q1)
 {
     ItemFetch f;
-    f.slot = d.hitems[v];
-    const ItemRec r = d.item_rec[v];
-    f.id = r.id; f.a_lo = r.a_lo; f.a_hi = r.a_hi; f.b_lo = r.b_lo; f.b_hi = r.b_hi; f.aux = r.aux; f.link = r.link;
-    f.c0 = lane < n ? d.vec[(size_t)v * FREE_MAX + lane] : 0u;
-    f.c1 = 64u + lane < n ? d.vec[(size_t)v * FREE_MAX + 64u + lane] : 0u;
+    f.slot = FX(x, 17); f.id = FX(x, 0); f.a_lo = FX(x, 1); f.a_hi = FX(x, 2); f.b_lo = FX(x, 3); f.b_hi = FX(x, 4); f.aux = FX(x, 5); f.link = FX(x, 6);
+    f.c0 = 0u; f.c1 = 0u;
+    if (f.slot != ITEM_UNUSED) {
+        item_counts(d, x, f.slot, lane, n, q0, q1, f.c0, f.c1);
+        const uint32_t own = FX(x, 7);
+        if (lane < n) f.c0 += iv_present(own, lane, q0);
+        if (64u + lane < n) f.c1 += iv_present(own, 64u + lane, q1);
+    }
     return f;
 }
 
@@ -1042,20 +1112,27 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     // the few wavefronts whose index matches the low ids of every range.)
     const uint32_t per_wave = ld(&ctrl->items_per_wave);
     const uint32_t v_lo = wave * per_wave, v_hi = min(v_lo + per_wave, n_items);
-    ItemFetch cur;
-    cur.slot = ITEM_UNUSED;
-    if (v_lo < v_hi) cur = fetch_item(d, v_lo, lane, n);
+    // three items in flight: the record of the one after next (by id), the slot records of the next (by its slot), this one
+    uint32_t id_cur = 0u, id_nxt = 0u, sl_cur = 0u;
+    if (v_lo < v_hi) id_cur = fetch_item(d, v_lo, lane);
+    if (v_lo + 1u < v_hi) id_nxt = fetch_item(d, v_lo + 1u, lane);
     for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
     for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
     __syncthreads();
     const uint32_t route_base = d.n_bld + d.n_room;
     WaveScratch &ws = wsc[threadIdx.x >> 6];
+    const Decision q0 = lane < n ? sm.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
+    const Decision q1 = 64u + lane < n ? sm.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
+    if (v_lo < v_hi) sl_cur = fetch_slot(d, FX(id_cur, 17), lane);
     const uint32_t pt1 = PROF_NOW();
     // (1) buildings and school rooms: one wavefront per item
     for (uint32_t v = v_lo; v < v_hi; ++v) {
-        const ItemFetch it = cur;
+        const uint32_t x = merge_fetch(id_cur, sl_cur, lane);
+        id_cur = id_nxt;
+        if (v + 2u < v_hi) id_nxt = fetch_item(d, v + 2u, lane);
+        if (v + 1u < v_hi) sl_cur = fetch_slot(d, FX(id_cur, 17), lane);
+        const ItemFetch it = decode_item(d, x, lane, n, q0, q1);
         if (it.slot == ITEM_UNUSED) break;
-        if (v + 1u < v_hi) cur = fetch_item(d, v + 1u, lane, n);
         if (it.id >= route_base) continue;
         const uint32_t pi0 = PROF_NOW();
         (void)pi0; ++p_items;
@@ -1077,7 +1154,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
             const uint32_t n_mem = it.a_hi - it.a_lo;
             uint32_t mm = 0u, mw = 0u;
             if (lane < n_mem) mm = d.room_idx[it.a_lo + lane];
-            school_counts(d, it.link, lane, n, ws);
+            school_counts(d, it.link, lane, n, q0, q1, ws);
             if (lane < n_mem) mw = d.cit[mm];
             const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws);
             __builtin_amdgcn_wave_barrier();
@@ -1216,26 +1293,32 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
     __syncthreads();
     WaveScratch &ws = wsc[threadIdx.x >> 6];
     const uint32_t *q_item = d.unit_item + (size_t)qr * d.unit_qcap, *q_lo = d.unit_lo + (size_t)qr * d.unit_qcap;
-    // three units in flight per wavefront: (item, first pair) of the one after next, the item record and counts of the
-    // next, the draws of this one
-    uint32_t code_a = UNIT_NOOP, plo_a = 0u, code_b = UNIT_NOOP, plo_b = 0u;
-    ItemFetch it_b;
-    it_b.slot = ITEM_UNUSED;
-    if (first < n_units) { code_b = q_item[first]; plo_b = q_lo[first]; }
-    if (first + step < n_units) { code_a = q_item[first + step]; plo_a = q_lo[first + step]; }
-    if (code_b != UNIT_NOOP) it_b = fetch_item(d, code_b & 0x3FFFFFFFu, lane, n);
+    // four units in flight per wavefront: (item, first pair) of the third from here, the item record of the one after next,
+    // the slot records of the next, the draws of this one
+    const Decision q0 = lane < n ? sm.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
+    const Decision q1 = 64u + lane < n ? sm.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
+    uint32_t code_0 = UNIT_NOOP, plo_0 = 0u, code_1 = UNIT_NOOP, plo_1 = 0u, code_2 = UNIT_NOOP, plo_2 = 0u;   // this, next, after next
+    uint32_t id_0 = 0u, id_1 = 0u, sl_0 = 0u;
+    if (first < n_units) { code_0 = q_item[first]; plo_0 = q_lo[first]; }
+    if (first + step < n_units) { code_1 = q_item[first + step]; plo_1 = q_lo[first + step]; }
+    if (first + 2u * step < n_units) { code_2 = q_item[first + 2u * step]; plo_2 = q_lo[first + 2u * step]; }
+    if (code_0 != UNIT_NOOP) id_0 = fetch_item(d, code_0 & 0x3FFFFFFFu, lane);
+    if (code_1 != UNIT_NOOP) id_1 = fetch_item(d, code_1 & 0x3FFFFFFFu, lane);
+    if (code_0 != UNIT_NOOP) sl_0 = fetch_slot(d, FX(id_0, 17), lane);
     for (uint32_t q = first; q < n_units; q += step) {
-        const uint32_t code = code_b, p_lo = plo_b;
-        const ItemFetch it = it_b;
-        code_b = code_a; plo_b = plo_a;
-        if (q + step < n_units && code_b != UNIT_NOOP) it_b = fetch_item(d, code_b & 0x3FFFFFFFu, lane, n);
-        code_a = UNIT_NOOP;
-        if (q + 2u * step < n_units) { code_a = q_item[q + 2u * step]; plo_a = q_lo[q + 2u * step]; }
+        const uint32_t code = code_0, p_lo = plo_0;
+        const uint32_t x = merge_fetch(id_0, sl_0, lane);
+        code_0 = code_1; plo_0 = plo_1; code_1 = code_2; plo_1 = plo_2; id_0 = id_1;
+        code_2 = UNIT_NOOP;
+        if (q + 3u * step < n_units) { code_2 = q_item[q + 3u * step]; plo_2 = q_lo[q + 3u * step]; }
+        if (code_1 != UNIT_NOOP) id_1 = fetch_item(d, code_1 & 0x3FFFFFFFu, lane);
+        if (code_0 != UNIT_NOOP) sl_0 = fetch_slot(d, FX(id_0, 17), lane);
         if (code == UNIT_NOOP) continue;
+        const ItemFetch it = decode_item(d, x, lane, n, q0, q1);
         const uint32_t kind = code >> 30;
         uint32_t lo, hi;
         const uint32_t *idx;
-        if (kind == 2u) { lo = it.a_lo; hi = it.a_hi; idx = d.room_idx; school_counts(d, it.link, lane, n, ws); }
+        if (kind == 2u) { lo = it.a_lo; hi = it.a_hi; idx = d.room_idx; school_counts(d, it.link, lane, n, q0, q1, ws); }
         else if (kind == 1u) { lo = it.b_lo; hi = it.b_hi; idx = d.wrk_idx; }
         else { lo = it.a_lo; hi = it.a_hi; idx = d.res_idx; }
         const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws);
@@ -1285,9 +1368,12 @@ __global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d)
     for (uint32_t v = wave; v < n_items; v += n_waves) {
         const uint32_t h = d.hitems[v];
         if (h == ITEM_UNUSED) continue;
-        d.vec[(size_t)v * FREE_MAX + lane] = 0u;
-        if (lane < FREE_MAX - 64u) d.vec[(size_t)v * FREE_MAX + 64u + lane] = 0u;
-        if (lane == 0) { d.hkey[h] = HKEY_EMPTY; d.hval[h] = HVAL_PENDING; }
+        const uint32_t state = d.slot_state[h], id = d.item_rec[v].id;
+        if (state > ITEM_RECS && id < d.n_bld + d.n_room) {                  // somebody spilled into the per-step counters
+            d.vec[(size_t)h * FREE_MAX + lane] = 0u;
+            if (lane < FREE_MAX - 64u) d.vec[(size_t)h * FREE_MAX + 64u + lane] = 0u;
+        }
+        if (lane == 0) { d.hkey[h] = HKEY_EMPTY; d.slot_state[h] = 0u; }
     }
 }
 

@@ -28,3 +28,7 @@ for target in (96, 192, 960, 1056, 1920, 2880, 3840, 4800, 4896, 4992):
     mt = us(r[:, 9] - r[:, 8])
     print("        marks: starts within %.1f us, span %.1f us | wave med %.1f max %.1f | waves with entries %d, most entries %d"
           % (us(r[:, 8].max() - m0), us(r[:, 9].max() - m0), np.median(mt), mt.max(), (r[:, 10] > 0).sum(), r[:, 10].max()))
+    b = r[:, 10] > 0
+    if b.any():
+        print("        marks stages (waves with entries, median / max us): prologue %.1f/%.1f | word ready %.1f/%.1f | probe %.1f/%.1f | claim %.1f/%.1f | "
+              "wait %.1f/%.1f | counts+pairs %.1f/%.1f" % tuple(x for i in (6, 11, 12, 13, 14, 15) for x in (np.median(us(r[b, i])), us(r[b, i]).max())))
