@@ -29,6 +29,7 @@ struct esim_ctx_impl {
     uint32_t *cnt_base = nullptr;
     uint32_t n_routes = 0;
     size_t xa_n = 0, xb_n = 0, xf_n = 0;
+    uint32_t last_chunk_pairs = 0;               // Infected during the chunk last looked at (picks the form of the chunk's book-keeping)
     uint32_t free_limit = 0, free_first = 0;     // open burst of decoupled chunks: last step it may reach, first step
     uint32_t host_t = 1;          // next time step to enqueue
     // device allocations
@@ -354,6 +355,8 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if ((rc = dev_alloc(c, &d.route_pairs, (size_t)d.items_cap * 2u))) return rc;
         if ((rc = dev_alloc(c, &d.route_pairs_big, (size_t)d.items_cap * 2u))) return rc;
         if ((rc = dev_alloc(c, &d.pair_cnt, 16384u))) return rc;
+        if ((rc = dev_alloc(c, &d.used_cnt, 16384u))) return rc;
+        HIP_TRY(c, hipMemset(d.used_cnt, 0, sizeof(uint32_t) * 16384u));
         if ((rc = dev_alloc(c, &d.hot, (size_t)HOT_COUNT * HOT_STRIDE))) return rc;
         HIP_TRY(c, hipMemset(d.hot, 0, sizeof(uint32_t) * HOT_COUNT * HOT_STRIDE));
         HIP_TRY(c, hipMemset(d.pair_cnt, 0, sizeof(uint32_t) * 16384u));
@@ -454,6 +457,7 @@ extern "C" int esim_reset(esim_ctx *ctx)
     if (n_seeds) HIP_TRY(c, hipMemcpy(d.log, c->init_log.data(), sizeof(uint32_t) * n_seeds, hipMemcpyHostToDevice));
     c->host_t = 1;
     c->free_limit = 0;
+    c->last_chunk_pairs = (uint32_t)c->init_log.size();
     c->phase_s[0] = c->phase_s[1] = c->phase_s[2] = 0;
     c->kev_used = 0;
     c->small_ms = 0; c->small_steps = 0;
@@ -610,16 +614,19 @@ int run_sequential(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, ui
 
 // The kernels of one time-parallel chunk; they take the chunk (first step, length, whether it may run this way)
 // from the control block as k_decide left it, and do nothing when it may not.
-void enqueue_parallel_chunk(esim_ctx_impl *c)
+// then_next: also prepare the chunk after it (census ahead + decisions: what k_future and k_decide do), for steps up to limit_t.
+// While few citizens are Infected the books, the log scatter, the clean-up and that preparation are ONE single-workgroup
+// kernel (a kernel boundary costs more than these steps); with many, the scatter and clean-up need the whole chip.
+void enqueue_parallel_chunk(esim_ctx_impl *c, bool then_next, uint32_t limit_t)
 {
     Dev &d = c->d;
+    const bool small = c->last_chunk_pairs < 1024u;
     hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
-    if (d.max_route > 64u) hipLaunchKernelGGL(k_chunk_routes_big, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
-    hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);
-    hipLaunchKernelGGL(k_chunk_finish, dim3(1), dim3(FIN_TPB), 0, c->stream, d);
-    hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d);
+    if (!small) hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, small ? 1 : 0, then_next ? 1 : 0, (uint32_t)c->xf_n, limit_t);
+    if (!small) hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d);
 }
 
 // One pipelined chunk.  Precondition: k_future ran for the current step (and, when sharded, buffer F was
@@ -635,13 +642,14 @@ int run_chunk(esim_ctx_impl *c, uint32_t n_ahead, uint32_t *executed, Ctrl *stat
     if (state_before) *state_before = h;
     if (h.error) return fail(c, -(int)h.error, "device-side error");
     const uint32_t n = h.chunk_ok, t0 = h.t;
+    c->last_chunk_pairs = h.chunk_pairs;
     *executed = 0;
     if (n == 0) return ESIM_OK;
     if (h.chunk_parallel) {
         // every step of the chunk in one pass: marks of all steps, draws of all (item, step) pairs, then the books
         const bool tk = c->kernel_timing;
         if (tk) { if (!c->cev[0]) { (void)hipEventCreate(&c->cev[0]); (void)hipEventCreate(&c->cev[1]); } HIP_TRY(c, hipEventRecord(c->cev[0], c->stream)); }
-        enqueue_parallel_chunk(c);
+        enqueue_parallel_chunk(c, false, 0u);
         if (tk) { HIP_TRY(c, hipEventRecord(c->cev[1], c->stream)); HIP_TRY(c, hipEventSynchronize(c->cev[1])); float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->cev[0], c->cev[1])); c->chunk_ms += ms; }
         HIP_TRY(c, hipGetLastError());
         c->chunk_steps += n; c->chunk_count++;
@@ -686,14 +694,12 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             // control block and is a no-op when the chunk cannot run time-parallel (then the steps simply do not advance,
             // which the read-back below sees, and the synchronous path further down takes over for one chunk).
             const uint32_t first = c->host_t, limit_t = first + remaining - 1u;
-            const uint32_t bursts = std::min<uint32_t>((remaining + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n, probing ? 1u : 64u);
+            const uint32_t bursts = std::min<uint32_t>((remaining + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n, probing ? 1u : 16u);   // (the form of a chunk's book-keeping is chosen from what the last read-back showed)
             const bool tk = c->kernel_timing;
             if (tk) { if (!c->cev[0]) { (void)hipEventCreate(&c->cev[0]); (void)hipEventCreate(&c->cev[1]); } HIP_TRY(c, hipEventRecord(c->cev[0], c->stream)); }
-            for (uint32_t g = 0; g < bursts; ++g) {
-                hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
-                hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1);
-                enqueue_parallel_chunk(c);
-            }
+            hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+            hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1);
+            for (uint32_t g = 0; g < bursts; ++g) enqueue_parallel_chunk(c, g + 1u < bursts, limit_t);
             if (tk) HIP_TRY(c, hipEventRecord(c->cev[1], c->stream));
             Ctrl h;
             HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -701,12 +707,13 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             HIP_TRY(c, hipGetLastError());
             if (h.error) return fail(c, -(int)h.error, "device-side error");
             const uint32_t done = h.t - first;
+            c->last_chunk_pairs = h.chunk_pairs;
             if (tk && done) { float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->cev[0], c->cev[1])); c->chunk_ms += ms; c->chunk_steps += done; c->chunk_count += (done + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n; }
             c->host_t = h.t; total += done; remaining -= done;
             if (h.finished) break;
             if (done == 0) { backoff = std::min<uint32_t>(64u, backoff ? backoff * 2u : 1u); sync_chunks_left = backoff; probing = true; }
-            else { backoff = 0; probing = h.t <= limit_t; }
-            if (h.t <= limit_t) stalled = true;                  // something other than a full time-parallel chunk is next
+            else { backoff = 0; probing = done < std::min<uint32_t>(remaining + done, bursts * (uint32_t)c->xf_n); }
+            if (done < std::min<uint32_t>(remaining + done, bursts * (uint32_t)c->xf_n)) stalled = true;   // something other than a full time-parallel chunk is next
             continue;
         }
         stalled = false;
@@ -811,7 +818,7 @@ extern "C" int esim_free_enqueue(esim_ctx *ctx)
         for (int i = 0; i < 2 && tk; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) tk = false; else c->fev.push_back(e); }
     if (tk) HIP_TRY(c, hipEventRecord(c->fev[c->fev_used], c->stream));
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d, (uint32_t)c->xf_n, c->free_limit, 1);
-    enqueue_parallel_chunk(c);
+    enqueue_parallel_chunk(c, false, 0u);
     if (tk) { HIP_TRY(c, hipEventRecord(c->fev[c->fev_used + 1], c->stream)); c->fev_used += 2; }
     HIP_TRY(c, hipGetLastError());
     return ESIM_OK;
@@ -828,6 +835,7 @@ extern "C" int esim_free_collect(esim_ctx *ctx, uint32_t *n_done)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (h.error) return fail(c, -(int)h.error, "device-side error");
     const uint32_t done = h.t - c->free_first;
+    c->last_chunk_pairs = h.chunk_pairs;
     // device time of the chunks of the burst (k_future and the collective in front of each are not inside the pairs)
     for (size_t i = 0; i + 1 < c->fev_used; i += 2) { float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->fev[i], c->fev[i + 1])); if (done) c->chunk_ms += ms; }
     c->fev_used = 0;

@@ -75,7 +75,8 @@ struct Ctrl {
     uint32_t n_units, unit_next; // deferred units of long member lists (k_chunk_units)
     uint32_t n_route_pairs;     // (route item, bus step) pairs with an Infected rider, routes of <= 64 riders
     uint32_t n_route_pairs_big; // ... routes of more riders
-    uint32_t chunk_done;        // the books of the last time-parallel chunk were written (k_chunk_finish)
+    uint32_t chunk_done;        // the books of the last time-parallel chunk were written (k_chunk_books)
+    uint32_t prev_t0, prev_n_items, prev_per_wave; // that chunk, for k_chunk_scatter
 };
 
 // An item of a time-parallel chunk: a building (a = residents, b = workers, aux = type), a school room (a =
@@ -125,6 +126,7 @@ struct Dev {
     uint32_t *route_pairs;      // [2 * items_cap] route << 7 | step of the chunk, routes of <= 64 riders: wavefront w of
                                 // k_chunk_marks owns entries [w * 2 * items_per_wave, ...), pair_cnt[w] of them are filled
     uint32_t *pair_cnt;         // [wavefronts of k_chunk_marks]
+    uint32_t *used_cnt;         // [wavefronts of k_chunk_marks] item ids the wavefront handed out
     uint32_t *route_pairs_big;  // [2 * items_cap] the same for longer routes, one shared list
     uint32_t unit_qcap;
     uint32_t *newexp;           // [SUBQ][newexp_cap] citizens exposed in the chunk, by id & 63
@@ -177,7 +179,9 @@ struct Dev {
 #define HOT_NEWEXP 0u              // [SUBQ] citizens exposed in the chunk, by citizen id & 63
 #define HOT_UNITS 64u              // [SUBQ] deferred units, by producing wavefront & 63
 #define HOT_BIGPAIRS 128u          // (route, bus step) pairs of routes with more than 64 riders
-#define HOT_COUNT 129u
+#define HOT_PREV_NEWEXP 129u       // [SUBQ] copy of HOT_NEWEXP of the chunk whose log entries k_chunk_scatter is writing
+#define HOT_RESET 129u             // counters k_decide zeroes for a new chunk
+#define HOT_COUNT 193u
 #define UNIT_NOOP 0xFFFFFFFFu
 #define CHUNK_BUS_STEPS 8u         // a one-pass chunk has at most this many steps with riders on a bus
 #define UNIT_PAIRS 256u            // (member, marked step) pairs per deferred unit of a long member list

@@ -504,16 +504,16 @@ __device__ __forceinline__ void block_scan_1024(uint32_t *v, uint32_t *wtmp)
     __syncthreads();
 }
 
-__global__ __launch_bounds__(FIN_TPB) void k_future(Dev d, uint32_t max_ahead, uint32_t limit_t)
+// (Control block, histogram and census vector are read past the caches: in k_chunk_books the same workgroup has just
+// written them.)
+__device__ __forceinline__ void future_body(const Dev &d, uint32_t max_ahead, uint32_t limit_t, uint32_t *win, uint32_t *wtmp)
 {
-    __shared__ uint32_t win[BF_WIN];
-    __shared__ uint32_t wtmp[FIN_TPB / 64];
     Ctrl *ctrl = d.ctrl;
-    const uint32_t t0 = ctrl->t, tid = threadIdx.x;                        // t0: first step of the chunk
+    const uint32_t t0 = ld(&ctrl->t), tid = threadIdx.x;                   // t0: first step of the chunk
     const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
     const int et = (int)d.exposed_time, it = (int)d.infected_time;
     const int base_idx = (int)(t0 + TE_BIAS) - et - 1 - it;               // lowest entry of the first Infected window
-    { const int k = base_idx + (int)tid; win[tid] = (k >= 0 && k < (int)TE_SLOTS) ? d.hist[k] : 0u; }
+    { const int k = base_idx + (int)tid; win[tid] = (k >= 0 && k < (int)TE_SLOTS) ? ld(&d.hist[k]) : 0u; }
     __syncthreads();
     block_scan_1024(win, wtmp);                                            // win[i] = sum of hist[base_idx .. base_idx + i]
     if (tid < n_ahead) {
@@ -535,6 +535,13 @@ __global__ __launch_bounds__(FIN_TPB) void k_future(Dev d, uint32_t max_ahead, u
     }
 }
 
+__global__ __launch_bounds__(FIN_TPB) void k_future(Dev d, uint32_t max_ahead, uint32_t limit_t)
+{
+    __shared__ uint32_t win[BF_WIN];
+    __shared__ uint32_t wtmp[FIN_TPB / 64];
+    future_body(d, max_ahead, limit_t, win, wtmp);
+}
+
 // Highest set bit index of m, -1 when m == 0.
 __device__ __forceinline__ int top_bit(unsigned long long m) { return m ? 63 - __clzll((long long)m) : -1; }
 
@@ -544,7 +551,7 @@ __device__ __forceinline__ uint32_t mask_compose(uint32_t g, uint32_t f)
     return ((g >> (2u * (f & 3u))) & 3u) | (((g >> (2u * ((f >> 2) & 3u))) & 3u) << 2) | (((g >> (2u * ((f >> 4) & 3u))) & 3u) << 4);
 }
 
-__global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32_t limit_t, int allow_parallel)
+__device__ __forceinline__ void decide_body(const Dev &d, uint32_t max_ahead, uint32_t limit_t, int allow_parallel)
 {
     // One wavefront, no serial loop.  Lane l evaluates the (strict) threshold tests of steps l and 64 + l
     // (interventions.rs:116-170).  Then, per step j of the chunk:
@@ -555,11 +562,11 @@ __global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32
     //                            exclusive scan of transition functions under composition
     Ctrl *ctrl = d.ctrl;
     const uint32_t lane = threadIdx.x;
-    const uint32_t t0 = ctrl->t;
+    const uint32_t t0 = ld(&ctrl->t);
     const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
     const uint32_t lim_in = n_ahead < FREE_MAX ? n_ahead : FREE_MAX;
-    const bool ok = !ctrl->have_elig && !ctrl->vacc_active && !ctrl->finished && !ctrl->error && ctrl->free_base == t0;
-    const uint32_t lock_init = ctrl->lockdown, mask_init = ctrl->mask, work_init = ctrl->at_work, bus_init = ctrl->bus_dir;
+    const bool ok = !ld(&ctrl->have_elig) && !ld(&ctrl->vacc_active) && !ld(&ctrl->finished) && !ld(&ctrl->error) && ld(&ctrl->free_base) == t0;
+    const uint32_t lock_init = ld(&ctrl->lockdown), mask_init = ld(&ctrl->mask), work_init = ld(&ctrl->at_work), bus_init = ld(&ctrl->bus_dir);
     unsigned long long m_vacc[2], m_lock[2];
     uint32_t f_mask[2];                                   // transition function of the lane's step in each round
     bool in[2];
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32
     for (int r = 0; r < 2; ++r) {
         const uint32_t j = 64u * r + lane;
         in[r] = j < lim_in && t0 + j <= d.max_steps;
-        const double x = in[r] ? (double)d.xf[j] / (double)d.n_global : 0.0;   // infected_percentage, statistics.rs:252
+        const double x = in[r] ? (double)ld(&d.xf[j]) / (double)d.n_global : 0.0;   // infected_percentage, statistics.rs:252
         m_vacc[r] = __ballot(in[r] && d.thr_vacc < x);
         m_lock[r] = __ballot(in[r] && d.thr_lockdown < x);
         const uint32_t from_none = (in[r] && d.thr_mask_pt < x) ? 1u : 0u;
@@ -656,17 +663,22 @@ __global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32
         if (lane == 0) d.dec[jn] = Decision{ lock_after, mask_after, aw_last, bd_last };
     }
     const unsigned long long bus_m0 = __ballot(lane < n_ok && mine[0].bus_dir != 0u), bus_m1 = __ballot(64u + lane < n_ok && mine[1].bus_dir != 0u);
-    for (uint32_t i = lane; i < HOT_COUNT; i += 64u) d.hot[i * HOT_STRIDE] = 0u;
+    for (uint32_t i = lane; i < HOT_RESET; i += 64u) d.hot[i * HOT_STRIDE] = 0u;
     if (lane == 0) {
         ctrl->chunk_ok = n_ok; ctrl->chunk_t0 = t0;
         // riders are on a bus in at most CHUNK_BUS_STEPS steps of a one-pass chunk (two a day unless a lockdown froze them
         // there, Q8): that bounds the (route, bus step) pairs a wavefront of k_chunk_marks can register.  The same on all shards.
         const uint32_t bus_steps = (uint32_t)(__popcll(bus_m0) + __popcll(bus_m1));
-        ctrl->chunk_parallel = (allow_parallel && d.xf[d.xf_n] == 0u && bus_steps <= CHUNK_BUS_STEPS) ? 1u : 0u;
+        ctrl->chunk_parallel = (allow_parallel && ld(&d.xf[d.xf_n]) == 0u && bus_steps <= CHUNK_BUS_STEPS) ? 1u : 0u;
         ctrl->n_items = 0u; ctrl->n_newexp = 0u; ctrl->n_units = 0u; ctrl->unit_next = 0u; ctrl->n_route_pairs = 0u; ctrl->n_route_pairs_big = 0u;
     }
     d.cursor[lane] = 0u;
     if (lane < FREE_MAX - 64u) d.cursor[64u + lane] = 0u;
+}
+
+__global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32_t limit_t, int allow_parallel)
+{
+    decide_body(d, max_ahead, limit_t, allow_parallel);
 }
 
 // Marks of the first step of a chunk (the later ones are made by the k_pipe of the step before).
@@ -902,7 +914,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         }
         { const uint32_t pf = PROF_NOW(); ps[0] += pb - pa; ps[1] += pc - pb; ps[2] += pd - pc; ps[3] += pe - pd; ps[4] += pf - pe; }
     }
-    if (lane == 0) d.pair_cnt[wave] = my_pairs;
+    if (lane == 0) { d.pair_cnt[wave] = my_pairs; d.used_cnt[wave] = next_id - wave * per_wave; }
     const uint32_t pm1 = PROF_NOW();
     PROF_PUT(d, 8, pm0); PROF_PUT(d, 9, pm1); PROF_PUT(d, 10, p_entries);
     PROF_PUT(d, 11, ps[0]); PROF_PUT(d, 12, ps[1]); PROF_PUT(d, 13, ps[2]); PROF_PUT(d, 14, ps[3]); PROF_PUT(d, 15, ps[4]);
@@ -1225,60 +1237,13 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     PROF_PUT(d, 4, p_items); PROF_PUT(d, 5, p_item_max);
 }
 
-// Routes of more than 64 riders: one workgroup per (route, bus step), ranks through LDS.  Launched only for
-// populations that have such a route.
-__global__ __launch_bounds__(TPB) void k_chunk_routes_big(Dev d)
-{
-    __shared__ RouteShared sm;
-    __shared__ Decision s_dec[FREE_MAX];
-    __shared__ uint64_t s_thr[512];
-    Ctrl *ctrl = d.ctrl;
-    const uint32_t t0 = ctrl->chunk_t0, n = ctrl->chunk_ok;
-    if (!ctrl->chunk_parallel || n == 0u) return;
-    const uint32_t n_pairs = min(ld(&d.hot[HOT_BIGPAIRS * HOT_STRIDE]), 2u * d.items_cap);
-    if (n_pairs == 0u) return;
-    for (uint32_t i = threadIdx.x; i < n; i += TPB) s_dec[i] = d.dec[i];
-    for (uint32_t i = threadIdx.x; i < 512u; i += TPB) s_thr[i] = d.thr[i];
-    __syncthreads();
-    const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
-    for (uint32_t q = blockIdx.x; q < n_pairs; q += gridDim.x) {
-        const uint32_t code = d.route_pairs_big[q], r = code >> 7, j = code & 127u;
-        const uint32_t off = d.route_off[r], sz = d.route_off[r + 1] - off;
-        const uint32_t s = t0 + j, mask = s_dec[j].mask;
-        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
-            const uint32_t c = d.route_riders[off + i];
-            sm.s_key[i] = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
-            sm.s_inf[i] = status_of(CW_TE(d.cit[c]), s, d.exposed_time, d.infected_time) == ESIM_INFECTED ? 1 : 0;
-        }
-        for (uint32_t i = threadIdx.x; i < sz / d.bus_capacity + 1u; i += TPB) sm.s_cnt[i] = 0u;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
-            const uint32_t ki = sm.s_key[i];
-            uint32_t rank = 0;
-            for (uint32_t qq = 0; qq < sz; ++qq) { const uint32_t kq = sm.s_key[qq]; rank += kq < ki || (kq == ki && qq < i); }
-            const uint32_t bus = rank / d.bus_capacity;
-            sm.s_bus[i] = (uint16_t)bus;
-            if (sm.s_inf[i]) atomicAdd(&sm.s_cnt[bus], 1u);
-        }
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
-            const uint32_t k = sm.s_cnt[sm.s_bus[i]];
-            if (!k) continue;
-            const uint32_t c = d.route_riders[off + i];
-            const uint32_t w = d.cit[c], te = CW_TE(w);
-            if (w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_FLAGS)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE)) continue;   // exposed before this bus
-            const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
-            if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < s_thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
-        }
-        __syncthreads();
-    }
-}
-
 // The deferred units of long member lists, dealt to the wavefronts round-robin.
+// Then the routes of more than 64 riders: one workgroup per (route, bus step), ranks through LDS.
 __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
 {
     __shared__ ChunkShared sm;
     __shared__ WaveScratch wsc[TPB / 64];
+    __shared__ RouteShared rs;
     Ctrl *ctrl = d.ctrl;
     const uint32_t t0 = ctrl->chunk_t0, n = ctrl->chunk_ok;
     if (!ctrl->chunk_parallel || n == 0u) return;
@@ -1287,7 +1252,8 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
     // queue `wave & 63`, every (n_waves / 64)-th unit of it
     const uint32_t qr = wave & (SUBQ - 1u), first = wave / SUBQ, step = n_waves / SUBQ;
     const uint32_t n_units = step ? min(ld(&d.hot[(HOT_UNITS + qr) * HOT_STRIDE]), d.unit_qcap) : 0u;
-    if (__syncthreads_or(first < n_units) == 0) return;
+    const uint32_t n_pairs = min(ld(&d.hot[HOT_BIGPAIRS * HOT_STRIDE]), 2u * d.items_cap);
+    if (__syncthreads_or(first < n_units) == 0 && n_pairs == 0u) return;
     for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
     for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
     __syncthreads();
@@ -1327,16 +1293,49 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
         member_pairs(d, ctrl, sm, ws, idx, lo, p_lo, min(pairs, p_lo + UNIT_PAIRS), lane, kind, S, t0);
         __builtin_amdgcn_wave_barrier();
     }
+    const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
+    for (uint32_t q = blockIdx.x; q < n_pairs; q += gridDim.x) {
+        const uint32_t code = d.route_pairs_big[q], r = code >> 7, j = code & 127u;
+        const uint32_t off = d.route_off[r], sz = d.route_off[r + 1] - off;
+        const uint32_t s = t0 + j, mask = sm.dec[j].mask;
+        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
+            const uint32_t c = d.route_riders[off + i];
+            rs.s_key[i] = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
+            rs.s_inf[i] = status_of(CW_TE(d.cit[c]), s, d.exposed_time, d.infected_time) == ESIM_INFECTED ? 1 : 0;
+        }
+        for (uint32_t i = threadIdx.x; i < sz / d.bus_capacity + 1u; i += TPB) rs.s_cnt[i] = 0u;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
+            const uint32_t ki = rs.s_key[i];
+            uint32_t rank = 0;
+            for (uint32_t qq = 0; qq < sz; ++qq) { const uint32_t kq = rs.s_key[qq]; rank += kq < ki || (kq == ki && qq < i); }
+            const uint32_t bus = rank / d.bus_capacity;
+            rs.s_bus[i] = (uint16_t)bus;
+            if (rs.s_inf[i]) atomicAdd(&rs.s_cnt[bus], 1u);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
+            const uint32_t k = rs.s_cnt[rs.s_bus[i]];
+            if (!k) continue;
+            const uint32_t c = d.route_riders[off + i];
+            const uint32_t w = d.cit[c], te = CW_TE(w);
+            if (w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_FLAGS)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE)) continue;   // exposed before this bus
+            const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
+            if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
+        }
+        __syncthreads();
+    }
 }
 
-// Exposures per step (statistics.rs:181) from the final citizen words.
+// Exposures per step (statistics.rs:181) from the final citizen words -- the many-workgroup form, for chunks with many new
+// exposures (k_chunk_books does it itself otherwise).
 __global__ __launch_bounds__(TPB) void k_chunk_count(Dev d)
 {
     if (!d.ctrl->chunk_parallel || d.ctrl->chunk_ok == 0u) return;
-    // sub-list `thread & 63`, every (threads / 64)-th entry of it
     const uint32_t tid = blockIdx.x * TPB + threadIdx.x, r = tid & (SUBQ - 1u), step = (gridDim.x * TPB) / SUBQ;
     const uint32_t n_new = min(ld(&d.hot[(HOT_NEWEXP + r) * HOT_STRIDE]), d.newexp_cap);
     const uint32_t *list = d.newexp + (size_t)r * d.newexp_cap;
+    // (exp_step of the chunk's steps is zero from reset / from nobody having written it: steps are visited once)
     for (uint32_t i = tid / SUBQ; i < n_new; i += step) {
         const uint32_t w = d.cit[list[i]];
         const uint32_t s = CW_TE(w) - TE_BIAS;
@@ -1349,12 +1348,13 @@ __global__ __launch_bounds__(TPB) void k_chunk_count(Dev d)
 __global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d)
 {
     Ctrl *ctrl = d.ctrl;
-    if (!ctrl->chunk_parallel || ctrl->chunk_done == 0u) return;
-    const uint32_t t0 = ctrl->chunk_t0;
-    const uint32_t n_items = min(ld(&ctrl->n_items), d.items_cap);
+    if (ctrl->chunk_done == 0u) return;
+    // (the chunk as k_chunk_books noted it down: by now the control block may describe the next one)
+    const uint32_t t0 = ctrl->prev_t0;
+    const uint32_t n_items = min(ctrl->prev_n_items, d.items_cap);
     {
         const uint32_t tid = blockIdx.x * TPB + threadIdx.x, r = tid & (SUBQ - 1u), step = (gridDim.x * TPB) / SUBQ;
-        const uint32_t n_new = min(ld(&d.hot[(HOT_NEWEXP + r) * HOT_STRIDE]), d.newexp_cap);
+        const uint32_t n_new = min(d.hot[(HOT_PREV_NEWEXP + r) * HOT_STRIDE], d.newexp_cap);
         const uint32_t *list = d.newexp + (size_t)r * d.newexp_cap;
         for (uint32_t i = tid / SUBQ; i < n_new; i += step) {
             const uint32_t m = list[i];
@@ -1362,18 +1362,20 @@ __global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d)
             d.log[d.log_off[te] + atomicAdd(&d.cursor[te - TE_BIAS - t0], 1u)] = m;
         }
     }
-    // a wavefront per item id: the count vectors and hash slots of the ids that were handed out
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
-    for (uint32_t v = wave; v < n_items; v += n_waves) {
-        const uint32_t h = d.hitems[v];
+    // the hash slots (and spilled count vectors) of the ids that were handed out: a thread per (wavefront of k_chunk_marks,
+    // k-th id of its range), so that the whole clean-up is three dependent loads deep
+    const uint32_t per_wave = ctrl->prev_per_wave, n_mw = per_wave ? n_items / per_wave : 0u;
+    const uint32_t tid = blockIdx.x * TPB + threadIdx.x, nth = gridDim.x * TPB;
+    for (uint32_t i = tid; i < n_mw * per_wave; i += nth) {
+        const uint32_t w = i / per_wave, k = i - w * per_wave;
+        if (k >= d.used_cnt[w]) continue;
+        const uint32_t h = d.hitems[i];
         if (h == ITEM_UNUSED) continue;
-        const uint32_t state = d.slot_state[h], id = d.item_rec[v].id;
-        if (state > ITEM_RECS && id < d.n_bld + d.n_room) {                  // somebody spilled into the per-step counters
-            d.vec[(size_t)h * FREE_MAX + lane] = 0u;
-            if (lane < FREE_MAX - 64u) d.vec[(size_t)h * FREE_MAX + 64u + lane] = 0u;
-        }
-        if (lane == 0) { d.hkey[h] = HKEY_EMPTY; d.slot_state[h] = 0u; }
+        const uint32_t state = d.slot_state[h];
+        if (state > ITEM_RECS && d.item_rec[i].id < d.n_bld + d.n_room)       // somebody spilled into the per-step counters
+            for (uint32_t j = 0; j < FREE_MAX; ++j) d.vec[(size_t)h * FREE_MAX + j] = 0u;
+        d.hkey[h] = HKEY_EMPTY;
+        if (state) d.slot_state[h] = 0u;
     }
 }
 
@@ -1382,7 +1384,9 @@ __global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d)
 // windows over the exposure histogram, the StatisticEntry of every step (statistics.rs:208-215, adjusted
 // by citizen_exposed :275-287), hist / log offsets, and the control block as it stands after the chunk.
 // (body shared by the two launch forms below)
-__device__ __forceinline__ void batch_finish_body(const Dev &d, uint32_t t0, uint32_t n)
+// e: this chunk's exposure counts [2 * step of the chunk + (bus ? 1 : 0)] when the caller holds them (else d.exp_step has them);
+// lo_out: receives the first log position of every step of the chunk.
+__device__ __forceinline__ void batch_finish_body(const Dev &d, uint32_t t0, uint32_t n, const uint32_t *e = nullptr, uint32_t *lo_out = nullptr)
 {
     __shared__ uint32_t P[BF_WIN + 1];                 // P[i + 1] = sum of H[0..i], P[0] = 0
     __shared__ uint32_t wtmp[FIN_TPB / 64];
@@ -1395,7 +1399,7 @@ __device__ __forceinline__ void batch_finish_body(const Dev &d, uint32_t t0, uin
     {
         const int k = base_idx + (int)tid;
         uint32_t h = 0;
-        if (k >= (int)(t0 + TE_BIAS)) { const uint32_t j = (uint32_t)(k - (int)(t0 + TE_BIAS)); if (j < n) h = d.exp_step[2u * (t0 + j)] + d.exp_step[2u * (t0 + j) + 1u]; }
+        if (k >= (int)(t0 + TE_BIAS)) { const uint32_t j = (uint32_t)(k - (int)(t0 + TE_BIAS)); if (j < n) h = e ? e[2u * j] + e[2u * j + 1u] : d.exp_step[2u * (t0 + j)] + d.exp_step[2u * (t0 + j) + 1u]; }
         else if (k >= 0) h = d.hist[k];
         P[tid + 1] = h;
         if (tid == 0) { P[0] = 0u; n_eff_s = n; }
@@ -1417,7 +1421,9 @@ __device__ __forceinline__ void batch_finish_body(const Dev &d, uint32_t t0, uin
         if (exps > S) ctrl->error = (uint32_t)(-ESIM_ESIM);               // citizen_exposed underflow, statistics.rs:275-287
         r.susceptible = S - exps; r.exposed = E + exps; r.infected = I;
         r.recovered = d.n - S - V - E - I; r.vaccinated = V;
-        r.exposures_building = d.exp_step[2u * s]; r.exposures_bus = d.exp_step[2u * s + 1u];
+        r.exposures_building = e ? e[2u * tid] : d.exp_step[2u * s]; r.exposures_bus = e ? e[2u * tid + 1u] : d.exp_step[2u * s + 1u];
+        if (e) { d.exp_step[2u * s] = r.exposures_building; d.exp_step[2u * s + 1u] = r.exposures_bus; }
+        if (lo_out) lo_out[tid] = run0 + (P[ts] - P[top0]);
         r.lockdown = d.dec[tid + 1u].lockdown; r.vaccination_active = 0u; r.mask_status = d.dec[tid + 1u].mask;
         r.n_riders = d.dec[tid].bus_dir ? d.n_pt : 0u; r.vaccinated_now = 0u; r.eligible_count = 0u;
         r.disease_exists = (r.exposed != 0u || r.infected != 0u || r.susceptible != 0u) ? 1u : 0u;   // statistics.rs:289-291
@@ -1452,19 +1458,104 @@ __global__ __launch_bounds__(FIN_TPB) void k_batch_finish(Dev d, uint32_t t0, ui
     batch_finish_body(d, t0, n);
 }
 
-// Time-parallel chunks take (t0, n) from the control block, so that the host can enqueue chunk after chunk without
-// waiting for k_decide; chunk_done tells k_chunk_scatter (and the host) that the books of this chunk were written.
-__global__ __launch_bounds__(FIN_TPB) void k_chunk_finish(Dev d)
+// The books of a one-pass chunk, in ONE workgroup so that nothing but kernel boundaries of the wide kernels is left on
+// the chunk's critical path (a kernel boundary costs ~4.5 us here, and these steps are small):
+//   exposures per step (statistics.rs:181) from the final citizen words of the newly exposed
+//   census, records, histogram, log offsets, control block (batch_finish_body)
+//   [scatter] the new log entries in step order; hash slots of the chunk's items emptied
+//   [next]    the census ahead and the decisions of the NEXT chunk (k_future + k_decide)
+// It takes (t0, n) from the control block, so that the host can enqueue chunk after chunk without waiting; chunk_done tells
+// k_chunk_scatter (the many-workgroup form of [scatter], used while many citizens are Infected) that the books were written.
+__global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int do_next, uint32_t max_ahead, uint32_t limit_t)
 {
+    __shared__ uint32_t e_cnt[2 * FREE_MAX];
+    __shared__ uint32_t lo_s[FREE_MAX], cur_s[FREE_MAX];
+    __shared__ uint32_t win[BF_WIN];
+    __shared__ uint32_t wtmp[FIN_TPB / 64];
     Ctrl *ctrl = d.ctrl;
-    if (!ctrl->chunk_parallel || ctrl->chunk_ok == 0u) { if (threadIdx.x == 0) ctrl->chunk_done = 0u; return; }
-    batch_finish_body(d, ctrl->chunk_t0, ctrl->chunk_ok);
-    if (threadIdx.x == 0) ctrl->chunk_done = 1u;
-    if (threadIdx.x < 64u) {
+    const uint32_t tid = threadIdx.x;
+    if (!ctrl->chunk_parallel || ctrl->chunk_ok == 0u) { if (tid == 0) ctrl->chunk_done = 0u; return; }
+    const uint32_t t0 = ctrl->chunk_t0, n = ctrl->chunk_ok;
+    const uint32_t n_items = min(ld(&ctrl->n_items), d.items_cap);
+    if (tid < 2u * FREE_MAX) e_cnt[tid] = 0u;
+    if (tid < FREE_MAX) cur_s[tid] = 0u;
+    __syncthreads();
+    // sub-list `thread & 63` of the newly exposed, every 16th entry of it
+    const uint32_t r = tid & (SUBQ - 1u);
+    const uint32_t n_new = min(ld(&d.hot[(HOT_NEWEXP + r) * HOT_STRIDE]), d.newexp_cap);
+    const uint32_t *list = d.newexp + (size_t)r * d.newexp_cap;
+    if (fused) {
+        for (uint32_t i = tid / SUBQ; i < n_new; i += FIN_TPB / SUBQ) {
+            const uint32_t w = d.cit[list[i]];
+            atomicAdd(&e_cnt[2u * (CW_TE(w) - TE_BIAS - t0) + ((w & CW_BUS_EXPOSED) ? 1u : 0u)], 1u);
+        }
+    } else if (tid < 2u * n) e_cnt[tid] = d.exp_step[2u * t0 + tid];           // k_chunk_count made them
+    __syncthreads();
+    batch_finish_body(d, t0, n, e_cnt, lo_s);
+    if (!fused) {
+        // k_chunk_scatter runs after this kernel, i.e. after the next chunk's decisions have reset what it reads: keep a copy
+        if (tid < SUBQ) d.hot[(HOT_PREV_NEWEXP + tid) * HOT_STRIDE] = n_new;   // (thread r < 64 read sub-list r's length above)
+        if (tid == 0) { ctrl->prev_t0 = t0; ctrl->prev_n_items = n_items; ctrl->prev_per_wave = ld(&ctrl->items_per_wave); }
+    }
+    if (tid == 0) ctrl->chunk_done = 1u;
+    if (tid < 64u) {
         // totals of the split lists, for esim_debug_counters
-        uint32_t a = ld(&d.hot[(HOT_NEWEXP + threadIdx.x) * HOT_STRIDE]), b = ld(&d.hot[(HOT_UNITS + threadIdx.x) * HOT_STRIDE]);
+        uint32_t a = ld(&d.hot[(HOT_NEWEXP + tid) * HOT_STRIDE]), b = ld(&d.hot[(HOT_UNITS + tid) * HOT_STRIDE]);
         for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-        if (threadIdx.x == 0) { ctrl->n_newexp = a; ctrl->n_units = b; ctrl->n_route_pairs_big = ld(&d.hot[HOT_BIGPAIRS * HOT_STRIDE]); }
+        if (tid == 0) { ctrl->n_newexp = a; ctrl->n_units = b; ctrl->n_route_pairs_big = ld(&d.hot[HOT_BIGPAIRS * HOT_STRIDE]); }
+    }
+    __syncthreads();
+    if (fused) {
+        for (uint32_t i = tid / SUBQ; i < n_new; i += FIN_TPB / SUBQ) {
+            const uint32_t m = list[i];
+            const uint32_t j = CW_TE(d.cit[m]) - TE_BIAS - t0;
+            d.log[lo_s[j] + atomicAdd(&cur_s[j], 1u)] = m;
+        }
+        // the ids each wavefront of k_chunk_marks handed out: thread t looks after the wavefronts t, t + 1024, ...; all loads
+        // of a round are in flight together (this loop is nothing but memory latency)
+        const uint32_t per_wave = ld(&ctrl->items_per_wave), n_mw = per_wave ? n_items / per_wave : 0u;
+        for (uint32_t w0 = tid; w0 < n_mw; w0 += 4u * FIN_TPB) {
+            uint32_t used[4], h[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { const uint32_t w = w0 + (uint32_t)a * FIN_TPB; used[a] = w < n_mw ? d.used_cnt[w] : 0u; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) h[a][k] = (uint32_t)k < used[a] ? d.hitems[(w0 + (uint32_t)a * FIN_TPB) * per_wave + (uint32_t)k] : ITEM_UNUSED;
+            uint32_t st[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) st[a][k] = h[a][k] != ITEM_UNUSED ? d.slot_state[h[a][k]] : 0u;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const uint32_t base = (w0 + (uint32_t)a * FIN_TPB) * per_wave;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t hs = h[a][k], state = st[a][k];
+                    if (hs == ITEM_UNUSED) continue;
+                    if (state > ITEM_RECS && d.item_rec[base + (uint32_t)k].id < d.n_bld + d.n_room)   // somebody spilled into the per-step counters
+                        for (uint32_t j = 0; j < FREE_MAX; ++j) d.vec[(size_t)hs * FREE_MAX + j] = 0u;
+                    d.hkey[hs] = HKEY_EMPTY;
+                    if (state) d.slot_state[hs] = 0u;
+                }
+                for (uint32_t k = 4u; k < used[a]; ++k) {                     // (more than four ids per wavefront: many Infected)
+                    const uint32_t hs = d.hitems[base + k];
+                    if (hs == ITEM_UNUSED) continue;
+                    const uint32_t state = d.slot_state[hs];
+                    if (state > ITEM_RECS && d.item_rec[base + k].id < d.n_bld + d.n_room)
+                        for (uint32_t j = 0; j < FREE_MAX; ++j) d.vec[(size_t)hs * FREE_MAX + j] = 0u;
+                    d.hkey[hs] = HKEY_EMPTY;
+                    if (state) d.slot_state[hs] = 0u;
+                }
+            }
+        }
+    }
+    if (do_next) {
+        __syncthreads();
+        future_body(d, max_ahead, limit_t, win, wtmp);
+        __syncthreads();
+        if (tid < 64u) decide_body(d, max_ahead, limit_t, 1);
     }
 }
 

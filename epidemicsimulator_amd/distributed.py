@@ -102,7 +102,7 @@ class ShardedSimulator:
                 _lib.check(self.lib.esim_set_exchange_buffer(self._ctx, which, C.c_void_p(t.data_ptr())), self._ctx)
                 self.xbuf.append(t)
             self.free_batch = int(self.xbuf[2].numel()) - 1     # the last word counts shards that need the per-step form
-            self.burst_max = 32                                 # chunks kept in flight between two host waits
+            self.burst_max = 16                                 # chunks kept in flight between two host waits
             self._burst, self._backoff, self._sync_left = 1, 0, 0
             torch.cuda.synchronize()
 
