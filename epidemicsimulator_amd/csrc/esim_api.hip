@@ -339,7 +339,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         HIP_TRY(c, hipMemset(d.slot_state, 0, sizeof(uint32_t) * cap));
         // deferred units: SUBQ queues; a queue that is full makes its producer draw the list itself, so the size is a
         // matter of speed only.  Room for the smaller of: every long member list marked in every step; a quarter of the
-        // citizens -- four times over, since the queues fill unevenly.
+        // citizens -- twice over, since the queues fill unevenly.
         size_t units = 0;
         auto add_lists = [&](const std::vector<uint32_t> &off) {
             for (size_t i = 0; i + 1 < off.size(); ++i) {
@@ -348,10 +348,9 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
             }
         };
         add_lists(res_off); add_lists(wrk_off); add_lists(room_off);
-        units = std::min<size_t>(units, (size_t)N / 4u + 65536u);
-        d.unit_qcap = (uint32_t)std::max<size_t>(1024, units * 4u / SUBQ);
-        if ((rc = dev_alloc(c, &d.unit_item, (size_t)d.unit_qcap * SUBQ))) return rc;
-        if ((rc = dev_alloc(c, &d.unit_lo, (size_t)d.unit_qcap * SUBQ))) return rc;
+        units = std::min<size_t>(units, (size_t)N / 8u + 65536u);
+        d.unit_qcap = (uint32_t)std::max<size_t>(1024, units * 2u / SUBQ);
+        if ((rc = dev_alloc(c, &d.units, (size_t)d.unit_qcap * SUBQ))) return rc;
         if ((rc = dev_alloc(c, &d.route_pairs, (size_t)d.items_cap * 2u))) return rc;
         if ((rc = dev_alloc(c, &d.route_pairs_big, (size_t)d.items_cap * 2u))) return rc;
         if ((rc = dev_alloc(c, &d.pair_cnt, 16384u))) return rc;

@@ -67,6 +67,7 @@ struct Ctrl {
     uint32_t small_done;        // steps executed by the last k_small launch
     uint32_t chunk_ok;          // steps of the current chunk that may run pipelined (k_decide)
     uint32_t chunk_t0;          // first step of the current chunk
+    uint32_t chunk_i0, chunk_i1; // log entries [i0, i1): exposure steps that are Infected in some step of the chunk
     uint32_t items_per_wave;    // item ids every wavefront of k_chunk_marks owns
     uint32_t chunk_parallel;    // 1: the chunk's marks fit the hash map, all its steps can be drawn in one pass
     uint32_t chunk_pairs;       // log entries that are Infected in some step of the chunk, this shard (k_future)
@@ -78,6 +79,10 @@ struct Ctrl {
     uint32_t chunk_done;        // the books of the last time-parallel chunk were written (k_chunk_books)
     uint32_t prev_t0, prev_n_items, prev_per_wave; // that chunk, for k_chunk_scatter
 };
+
+// A deferred unit of a long member list: UNIT_PAIRS (member, marked step) pairs from pair p_lo on.  code = kind << 30 | p_lo
+// (UNIT_NOOP: skip); m_first = the member its first pair belongs to.
+struct UnitRec { uint32_t slot, link, lo, n_mem, code, own, m_first, pad; };
 
 // An item of a time-parallel chunk: a building (a = residents, b = workers, aux = type), a school room (a =
 // participants, aux = its school building) or a route.
@@ -122,7 +127,7 @@ struct Dev {
     uint32_t *slot_iv;          // [hcap][8] interval records (k_chunk_marks: IV_*)
     uint32_t *vec;              // [hcap][FREE_MAX] per-step counts of the Infected that found no record free
     uint32_t items_cap;
-    uint32_t *unit_item, *unit_lo;  // [SUBQ][unit_qcap] item | kind << 30 (UNIT_NOOP: skip), first pair of the unit
+    struct UnitRec *units;      // [SUBQ][unit_qcap] deferred units of long member lists
     uint32_t *route_pairs;      // [2 * items_cap] route << 7 | step of the chunk, routes of <= 64 riders: wavefront w of
                                 // k_chunk_marks owns entries [w * 2 * items_per_wave, ...), pair_cnt[w] of them are filled
     uint32_t *pair_cnt;         // [wavefronts of k_chunk_marks]

@@ -666,6 +666,11 @@ __device__ __forceinline__ void decide_body(const Dev &d, uint32_t max_ahead, ui
     for (uint32_t i = lane; i < HOT_RESET; i += 64u) d.hot[i * HOT_STRIDE] = 0u;
     if (lane == 0) {
         ctrl->chunk_ok = n_ok; ctrl->chunk_t0 = t0;
+        // the log slice of everybody Infected in some step of the chunk (k_chunk_marks starts from it)
+        const int lo_te = (int)(t0 + TE_BIAS) - (int)d.exposed_time - 1 - (int)d.infected_time;
+        const int hi_te = (int)(t0 + n_ok + TE_BIAS) - (int)d.exposed_time - 2;
+        ctrl->chunk_i0 = (hi_te < 0 || n_ok == 0u) ? 0u : ld(&d.log_off[lo_te < 0 ? 0 : lo_te]);
+        ctrl->chunk_i1 = (hi_te < 0 || n_ok == 0u) ? 0u : ld(&d.log_off[hi_te + 1]);
         // riders are on a bus in at most CHUNK_BUS_STEPS steps of a one-pass chunk (two a day unless a lockdown froze them
         // there, Q8): that bounds the (route, bus step) pairs a wavefront of k_chunk_marks can register.  The same on all shards.
         const uint32_t bus_steps = (uint32_t)(__popcll(bus_m0) + __popcll(bus_m1));
@@ -786,11 +791,9 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         for (uint32_t i = tid; i < ort; i += nth) d.route_flag[q][d.touched_route[q][i]] = 0u;
         for (uint32_t i = tid; i < orb; i += nth) d.route_flag[q][d.touched_route_big[q][i]] = 0u;
     }
-    const int lo_te = (int)(t0 + TE_BIAS) - (int)d.exposed_time - 1 - (int)d.infected_time;     // Infected in step t0
-    const int hi_te = (int)(t0 + n - 1u + TE_BIAS) - (int)d.exposed_time - 1;                    // Infected in step t0 + n - 1
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
-    const uint32_t i0 = hi_te < 0 ? 0u : d.log_off[lo_te < 0 ? 0 : lo_te], i1 = hi_te < 0 ? 0u : d.log_off[hi_te + 1];
+    const uint32_t i0 = ctrl->chunk_i0, i1 = ctrl->chunk_i1;                 // log slice of the chunk's Infected (k_decide)
     // every wavefront owns a fixed range of item ids (a citizen claims at most four items), so no counter is shared
     const uint32_t per_wave = 4u * ((i1 - i0 + n_waves - 1u) / n_waves);
     if (wave == 0 && lane == 0) { ctrl->items_per_wave = per_wave; ctrl->n_items = per_wave * n_waves; }
@@ -851,29 +854,39 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
             const uint32_t id = (uint32_t)key;
             // (a school's counts are looked up by slot from its rooms, so even its claimer's stretch goes into a slot record)
             ItemRec rec = { id, 0u, 0u, 0u, 0u, 0u, lane == 2u ? s_work : 0xFFFFFFFFu, (lane < 3u && !(lane == 1u && school)) ? iv : 0u };
-            if (id < d.n_bld) { rec.a_lo = d.res_off[id]; rec.a_hi = d.res_off[id + 1]; rec.b_lo = d.wrk_off[id]; rec.b_hi = d.wrk_off[id + 1]; rec.aux = d.bld_type[id]; }
-            else if (id < d.n_bld + d.n_room) { const uint32_t r = id - d.n_bld; rec.a_lo = d.room_off[r]; rec.a_hi = d.room_off[r + 1]; rec.aux = d.room_bld[r]; }
+            // (pointer selects, not branches: the loads of a building lane and of a room lane go out together)
+            const bool is_bld = id < d.n_bld, is_room = !is_bld && id < d.n_bld + d.n_room;
+            if (is_bld || is_room) {
+                const uint32_t r = is_bld ? id : id - d.n_bld;
+                const uint32_t *pa = (is_bld ? d.res_off : d.room_off) + r;
+                const uint32_t a_lo = pa[0], a_hi = pa[1];
+                const uint32_t b_lo = is_bld ? d.wrk_off[r] : 0u, b_hi = is_bld ? d.wrk_off[r + 1] : 0u;
+                const uint32_t aux = is_bld ? (uint32_t)d.bld_type[r] : d.room_bld[r];
+                rec.a_lo = a_lo; rec.a_hi = a_hi; rec.b_lo = b_lo; rec.b_hi = b_hi; rec.aux = aux;
+            }
             d.item_rec[v] = rec;
         }
         next_id += (uint32_t)__popcll(cm);
         const uint32_t pd = PROF_NOW();
-        // somebody else's building / room: my stretch goes into one of the slot's ITEM_RECS records; when they are taken,
-        // into its per-step counters (`vec`), one atomic per step
-        bool spill = false;
-        if (lane < 3u && (pending || (claimed && lane == 1u && school))) {
-            const uint32_t pos = atomicAdd(&d.slot_state[slot], 1u);
-            if (pos < ITEM_RECS) d.slot_iv[(size_t)slot * 8u + pos] = iv; else spill = true;
-        }
-        // the route: which of my bus steps nobody has registered yet
-        uint32_t new_bits = 0u;
+        // Somebody else's building / room: my stretch goes into one of the slot's ITEM_RECS records; when they are taken,
+        // into its per-step counters (`vec`), one atomic per step.  The route: which of my bus steps nobody has registered yet.
+        uint32_t mine = 0u;                                                   // bit i: I ride, Infected, in the i-th bus step of the chunk
         if (any_bus) {
             const unsigned long long r0 = __ballot((p0 & 4u) != 0u), r1 = __ballot((p1 & 4u) != 0u);
-            uint32_t mine = 0u;                                               // bit i: I ride, Infected, in the i-th bus step of the chunk
             for (unsigned long long m = busm0 & r0; m; m &= m - 1ull) mine |= 1u << __popcll(busm0 & ((m & (0ull - m)) - 1ull));
             for (unsigned long long m = busm1 & r1; m; m &= m - 1ull) mine |= 1u << (__popcll(busm0) + __popcll(busm1 & ((m & (0ull - m)) - 1ull)));
-            if (lane == 3u) new_bits = mine & ~atomicOr(&d.slot_state[slot], mine);
-            new_bits = __shfl(new_bits, 3, 64);
         }
+        const bool add_rec = lane < 3u && (pending || (claimed && lane == 1u && school));
+        const bool reg_bus = lane == 3u && any_bus;
+        uint32_t old = 0u;
+        if (add_rec || reg_bus) {
+            // lanes 0..2 take a record position (+1), lane 3 sets its bus-step bits: two atomic instructions, one wait
+            if (reg_bus) old = atomicOr(&d.slot_state[slot], mine);
+            else old = atomicAdd(&d.slot_state[slot], 1u);
+        }
+        bool spill = false;
+        if (add_rec) { if (old < ITEM_RECS) d.slot_iv[(size_t)slot * 8u + old] = iv; else spill = true; }
+        const uint32_t new_bits = __shfl(reg_bus ? (mine & ~old) : 0u, 3, 64);
         const bool sp_home = __shfl((int)spill, 0, 64), sp_work = __shfl((int)spill, 1, 64), sp_room = __shfl((int)spill, 2, 64);
         const uint32_t pe = PROF_NOW();
         if (sp_home) {
@@ -948,10 +961,10 @@ struct WaveScratch { uint32_t cnt[FREE_MAX]; uint32_t sch[FREE_MAX]; uint32_t me
 // spread densely over the 64 lanes (the draws are Philox-bound -- 20 quarter-rate multiplies each -- so idle lanes
 // are what costs).  ws.steps: the item's marked steps in order, S of them; ws.cnt / ws.sch: the item's / the school's
 // Infected per step.  kind 0 residents, 1 workers, 2 room participants.
-// pre_m / pre_w: members lo + lane of the list and their words when the caller has already fetched them (have_pre).
+// pre_m / pre_w: members lo + pre_base + lane of the list and their words when the caller has already fetched them (have_pre).
 __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, WaveScratch &ws, const uint32_t *idx,
                                              uint32_t lo, uint32_t p_lo, uint32_t p_hi, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0,
-                                             bool have_pre = false, uint32_t pre_m = 0u, uint32_t pre_w = 0u)
+                                             bool have_pre = false, uint32_t pre_m = 0u, uint32_t pre_w = 0u, uint32_t pre_base = 0u)
 {
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
     // members touched by the pairs [p_lo, p_hi): staged in LDS 64 at a time -- every member recurs once per marked step
@@ -959,7 +972,7 @@ __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const Chu
     for (uint32_t mb = m_first; mb <= m_last; mb += 64u) {
         __builtin_amdgcn_wave_barrier();
         if (mb + lane <= m_last) {
-            if (have_pre && mb == 0u) { ws.mem_id[lane] = pre_m; ws.mem_w[lane] = pre_w; }
+            if (have_pre && mb == pre_base) { ws.mem_id[lane] = pre_m; ws.mem_w[lane] = pre_w; }
             else {
                 const uint32_t m = idx ? idx[lo + mb + lane] : lo + mb + lane;
                 ws.mem_id[lane] = m;
@@ -1020,8 +1033,12 @@ __device__ __forceinline__ void school_counts(const Dev &d, uint32_t s_sch, uint
 
 // Lists with more pairs than this are cut into units that any wavefront can take (k_chunk_units), so that one
 // 200-member workplace does not keep a single wavefront busy while the chip idles.
+// A deferred unit carries everything its consumer needs, so that it is three dependent loads away from drawing: the
+// item's hash slot and its claimer's stretch (the Infected per step), the school's slot for a room, the member list, and
+// where in it the unit's first pair falls.
+struct UnitSrc { uint32_t slot, link, own; };
 __device__ __forceinline__ void list_or_units(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, WaveScratch &ws, const uint32_t *idx,
-                                              uint32_t lo, uint32_t hi, uint32_t v, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0,
+                                              uint32_t lo, uint32_t hi, const UnitSrc &src, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0,
                                               bool have_pre = false, uint32_t pre_m = 0u, uint32_t pre_w = 0u)
 {
     const uint32_t pairs = (hi - lo) * S;
@@ -1032,16 +1049,16 @@ __device__ __forceinline__ void list_or_units(const Dev &d, Ctrl *ctrl, const Ch
     uint32_t start = 0;
     if (lane == 0) start = atomicAdd(&d.hot[(HOT_UNITS + r) * HOT_STRIDE], n_units);
     start = __shfl(start, 0, 64);
-    uint32_t *q_item = d.unit_item + (size_t)r * d.unit_qcap, *q_lo = d.unit_lo + (size_t)r * d.unit_qcap;
+    UnitRec *q = d.units + (size_t)r * d.unit_qcap;
     if (start + n_units > d.unit_qcap) {
         // queue full: what was reserved of it becomes no-ops and the list is drawn here
-        for (uint32_t i = lane; i < n_units && start + i < d.unit_qcap; i += 64u) q_item[start + i] = UNIT_NOOP;
+        for (uint32_t i = lane; i < n_units && start + i < d.unit_qcap; i += 64u) q[start + i].code = UNIT_NOOP;
         member_pairs(d, ctrl, sm, ws, idx, lo, 0u, pairs, lane, kind, S, t0, have_pre, pre_m, pre_w);
         return;
     }
     for (uint32_t i = lane; i < n_units; i += 64u) {
-        q_item[start + i] = v | (kind << 30);
-        q_lo[start + i] = i * UNIT_PAIRS;
+        const uint32_t p_lo = i * UNIT_PAIRS;
+        q[start + i] = UnitRec{ src.slot, kind == 2u ? src.link : 0xFFFFFFFFu, lo, hi - lo, (kind << 30) | p_lo, src.own, p_lo / S, 0u };
     }
 }
 
@@ -1128,6 +1145,16 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     uint32_t id_cur = 0u, id_nxt = 0u, sl_cur = 0u;
     if (v_lo < v_hi) id_cur = fetch_item(d, v_lo, lane);
     if (v_lo + 1u < v_hi) id_nxt = fetch_item(d, v_lo + 1u, lane);
+    // ... and the first look at the (route, bus step) pairs dealt to this wavefront (phase 2 below), so that they are here
+    // when the items are done
+    const uint32_t K = 2u * per_wave;                                          // pairs a stretch of the list can hold
+    uint32_t code_l = 0u, off_l = 0u, sz_l = 0u;
+    bool have = false;
+    if (lane < K) {
+        const uint32_t src = (wave + n_waves - (uint32_t)(((unsigned long long)lane * PAIR_SPREAD) % n_waves)) % n_waves;
+        have = lane < d.pair_cnt[src];
+        code_l = d.route_pairs[(size_t)src * K + lane];                       // in bounds whether or not the pair exists
+    }
     for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
     for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
     __syncthreads();
@@ -1136,6 +1163,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     const Decision q0 = lane < n ? sm.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
     const Decision q1 = 64u + lane < n ? sm.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
     if (v_lo < v_hi) sl_cur = fetch_slot(d, FX(id_cur, 17), lane);
+    if (have) { const uint32_t r = code_l >> 7; off_l = d.route_off[r]; sz_l = d.route_off[r + 1] - off_l; }
     const uint32_t pt1 = PROF_NOW();
     // (1) buildings and school rooms: one wavefront per item
     for (uint32_t v = v_lo; v < v_hi; ++v) {
@@ -1160,8 +1188,9 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
             const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws);
             __builtin_amdgcn_wave_barrier();
             // Household / Workplace::find_exposures: every registered occupant (building.rs:202-204,278-280)
-            list_or_units(d, ctrl, sm, ws, d.res_idx, it.a_lo, it.a_hi, v, lane, 0u, S, t0, true, rm, rw);
-            list_or_units(d, ctrl, sm, ws, d.wrk_idx, it.b_lo, it.b_hi, v, lane, 1u, S, t0, true, wm, ww);
+            const UnitSrc src = { it.slot, it.link, FX(x, 7) };
+            list_or_units(d, ctrl, sm, ws, d.res_idx, it.a_lo, it.a_hi, src, lane, 0u, S, t0, true, rm, rw);
+            list_or_units(d, ctrl, sm, ws, d.wrk_idx, it.b_lo, it.b_hi, src, lane, 1u, S, t0, true, wm, ww);
         } else {
             const uint32_t n_mem = it.a_hi - it.a_lo;
             uint32_t mm = 0u, mw = 0u;
@@ -1171,7 +1200,8 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
             const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws);
             __builtin_amdgcn_wave_barrier();
             // School::find_exposures: the room once per infected in it (building.rs:494-522)
-            list_or_units(d, ctrl, sm, ws, d.room_idx, it.a_lo, it.a_hi, v, lane, 2u, S, t0, true, mm, mw);
+            const UnitSrc src = { it.slot, it.link, FX(x, 7) };
+            list_or_units(d, ctrl, sm, ws, d.room_idx, it.a_lo, it.a_hi, src, lane, 2u, S, t0, true, mm, mw);
         }
         __builtin_amdgcn_wave_barrier();
         { const uint32_t dt = PROF_NOW() - pi0; p_item_max = dt > p_item_max ? dt : p_item_max; }
@@ -1183,17 +1213,17 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     // Wavefront w of k_chunk_marks left pair_cnt[w] pairs in its own stretch of the list.  They are dealt out so that the
     // k-th pair of w goes to wavefront (w + k * PAIR_SPREAD) mod n_waves: here lane k looks at the stretch it may have
     // been dealt from, and the wavefront then takes the pairs that exist one by one.
-    const uint32_t K = 2u * per_wave;                                          // pairs a stretch can hold
     for (uint32_t k0 = 0; k0 < K; k0 += 64u) {
-        const uint32_t kk = k0 + lane;
-        uint32_t code_l = 0u, off_l = 0u, sz_l = 0u;
-        bool have = false;
-        if (kk < K) {
-            const uint32_t src = (wave + n_waves - (uint32_t)(((unsigned long long)kk * PAIR_SPREAD) % n_waves)) % n_waves;
-            have = kk < d.pair_cnt[src];
-            code_l = d.route_pairs[(size_t)src * K + kk];                      // in bounds whether or not the pair exists
+        if (k0) {                                                             // (beyond the 64 looked at up front: many Infected)
+            const uint32_t kk = k0 + lane;
+            have = false;
+            if (kk < K) {
+                const uint32_t src = (wave + n_waves - (uint32_t)(((unsigned long long)kk * PAIR_SPREAD) % n_waves)) % n_waves;
+                have = kk < d.pair_cnt[src];
+                code_l = d.route_pairs[(size_t)src * K + kk];
+            }
+            if (have) { const uint32_t r = code_l >> 7; off_l = d.route_off[r]; sz_l = d.route_off[r + 1] - off_l; }
         }
-        if (have) { const uint32_t r = code_l >> 7; off_l = d.route_off[r]; sz_l = d.route_off[r + 1] - off_l; }
         unsigned long long todo = __ballot(have);
         while (todo) {
         const int src_lane = __ffsll((long long)todo) - 1;
@@ -1233,8 +1263,10 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
         }
     }
     const uint32_t pt3 = PROF_NOW();
+#ifndef ESIM_PROFILE_UNITS
     PROF_PUT(d, 0, pt0); PROF_PUT(d, 1, pt1); PROF_PUT(d, 2, pt2); PROF_PUT(d, 3, pt3);   // start, after preamble, after items, end
     PROF_PUT(d, 4, p_items); PROF_PUT(d, 5, p_item_max);
+#endif
 }
 
 // The deferred units of long member lists, dealt to the wavefronts round-robin.
@@ -1249,6 +1281,8 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
     if (!ctrl->chunk_parallel || n == 0u) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    const uint32_t pu0 = PROF_NOW();
+    uint32_t pu_n = 0u, pu_max = 0u, pu_it = 0u;
     // queue `wave & 63`, every (n_waves / 64)-th unit of it
     const uint32_t qr = wave & (SUBQ - 1u), first = wave / SUBQ, step = n_waves / SUBQ;
     const uint32_t n_units = step ? min(ld(&d.hot[(HOT_UNITS + qr) * HOT_STRIDE]), d.unit_qcap) : 0u;
@@ -1258,41 +1292,59 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
     for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
     __syncthreads();
     WaveScratch &ws = wsc[threadIdx.x >> 6];
-    const uint32_t *q_item = d.unit_item + (size_t)qr * d.unit_qcap, *q_lo = d.unit_lo + (size_t)qr * d.unit_qcap;
-    // four units in flight per wavefront: (item, first pair) of the third from here, the item record of the one after next,
-    // the slot records of the next, the draws of this one
+    const uint32_t *q_words = reinterpret_cast<const uint32_t *>(d.units + (size_t)qr * d.unit_qcap);
     const Decision q0 = lane < n ? sm.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
     const Decision q1 = 64u + lane < n ? sm.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
-    uint32_t code_0 = UNIT_NOOP, plo_0 = 0u, code_1 = UNIT_NOOP, plo_1 = 0u, code_2 = UNIT_NOOP, plo_2 = 0u;   // this, next, after next
-    uint32_t id_0 = 0u, id_1 = 0u, sl_0 = 0u;
-    if (first < n_units) { code_0 = q_item[first]; plo_0 = q_lo[first]; }
-    if (first + step < n_units) { code_1 = q_item[first + step]; plo_1 = q_lo[first + step]; }
-    if (first + 2u * step < n_units) { code_2 = q_item[first + 2u * step]; plo_2 = q_lo[first + 2u * step]; }
-    if (code_0 != UNIT_NOOP) id_0 = fetch_item(d, code_0 & 0x3FFFFFFFu, lane);
-    if (code_1 != UNIT_NOOP) id_1 = fetch_item(d, code_1 & 0x3FFFFFFFu, lane);
-    if (code_0 != UNIT_NOOP) sl_0 = fetch_slot(d, FX(id_0, 17), lane);
+    // Per unit: its record (lanes 0..7 of one register); then, together, the slot's interval records, the school's, and the
+    // ids of the first members its pairs touch; then those members' words.  The record of the unit after next and the
+    // second stage of the next are in flight while this one draws.
+    auto unit_words = [&](uint32_t q) -> uint32_t { return lane < 8u ? q_words[(size_t)q * 8u + lane] : 0u; };
+    auto member_id = [&](uint32_t u) -> uint32_t {
+        const uint32_t code = FX(u, 4), kind = code >> 30, lo = FX(u, 2), n_mem = FX(u, 3), mf = FX(u, 6);
+        if (code == UNIT_NOOP || mf + lane >= n_mem) return 0u;
+        const uint32_t *idx = kind == 2u ? d.room_idx : kind == 1u ? d.wrk_idx : d.res_idx;
+        return idx ? idx[lo + mf + lane] : lo + mf + lane;
+    };
+    const uint32_t pu1 = PROF_NOW();
+    uint32_t u_0 = 0xFFFFFFFFu, u_1 = 0xFFFFFFFFu;                            // this unit, the next (code word UNIT_NOOP: none)
+    uint32_t xs_0 = 0u, ys_0 = 0u, mid_0 = 0u;
+    if (first < n_units) u_0 = unit_words(first);
+    if (first + step < n_units) u_1 = unit_words(first + step);
+    if (first < n_units && FX(u_0, 4) != UNIT_NOOP) { xs_0 = fetch_slot(d, FX(u_0, 0), lane); ys_0 = fetch_slot(d, FX(u_0, 1), lane); mid_0 = member_id(u_0); }
     for (uint32_t q = first; q < n_units; q += step) {
-        const uint32_t code = code_0, p_lo = plo_0;
-        const uint32_t x = merge_fetch(id_0, sl_0, lane);
-        code_0 = code_1; plo_0 = plo_1; code_1 = code_2; plo_1 = plo_2; id_0 = id_1;
-        code_2 = UNIT_NOOP;
-        if (q + 3u * step < n_units) { code_2 = q_item[q + 3u * step]; plo_2 = q_lo[q + 3u * step]; }
-        if (code_1 != UNIT_NOOP) id_1 = fetch_item(d, code_1 & 0x3FFFFFFFu, lane);
-        if (code_0 != UNIT_NOOP) sl_0 = fetch_slot(d, FX(id_0, 17), lane);
+        const uint32_t u = u_0, xs = xs_0, ys = ys_0, mid = mid_0;
+        u_0 = u_1;
+        u_1 = 0xFFFFFFFFu;
+        if (q + 2u * step < n_units) u_1 = unit_words(q + 2u * step);
+        if (q + step < n_units && FX(u_0, 4) != UNIT_NOOP) { xs_0 = fetch_slot(d, FX(u_0, 0), lane); ys_0 = fetch_slot(d, FX(u_0, 1), lane); mid_0 = member_id(u_0); }
+        const uint32_t code = FX(u, 4);
         if (code == UNIT_NOOP) continue;
-        const ItemFetch it = decode_item(d, x, lane, n, q0, q1);
-        const uint32_t kind = code >> 30;
-        uint32_t lo, hi;
-        const uint32_t *idx;
-        if (kind == 2u) { lo = it.a_lo; hi = it.a_hi; idx = d.room_idx; school_counts(d, it.link, lane, n, q0, q1, ws); }
-        else if (kind == 1u) { lo = it.b_lo; hi = it.b_hi; idx = d.wrk_idx; }
-        else { lo = it.a_lo; hi = it.a_hi; idx = d.res_idx; }
-        const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws);
+        const uint32_t pui = PROF_NOW();
+        ++pu_n;
+        const uint32_t kind = code >> 30, p_lo = code & 0x3FFFFFFFu, slot = FX(u, 0), link = FX(u, 1), lo = FX(u, 2), n_mem = FX(u, 3), own = FX(u, 5), mf = FX(u, 6);
+        const uint32_t mw = (mf + lane < n_mem) ? d.cit[mid] : 0u;
+        uint32_t c0, c1;
+        item_counts(d, xs, slot, lane, n, q0, q1, c0, c1);
+        if (lane < n) c0 += iv_present(own, lane, q0);
+        if (64u + lane < n) c1 += iv_present(own, 64u + lane, q1);
+        if (kind == 2u) {
+            uint32_t s0 = 0u, s1 = 0u;
+            if (link != 0xFFFFFFFFu) item_counts(d, ys, link, lane, n, q0, q1, s0, s1);
+            ws.sch[lane] = s0;
+            if (lane < FREE_MAX - 64u) ws.sch[64u + lane] = s1;
+        }
+        const uint32_t *idx = kind == 2u ? d.room_idx : kind == 1u ? d.wrk_idx : d.res_idx;
+        const uint32_t S = item_steps_regs(c0, c1, lane, ws);
         __builtin_amdgcn_wave_barrier();
-        const uint32_t pairs = (hi - lo) * S;
-        member_pairs(d, ctrl, sm, ws, idx, lo, p_lo, min(pairs, p_lo + UNIT_PAIRS), lane, kind, S, t0);
+        const uint32_t pairs = n_mem * S;
+        member_pairs(d, ctrl, sm, ws, idx, lo, p_lo, min(pairs, p_lo + UNIT_PAIRS), lane, kind, S, t0, true, mid, mw, mf);
         __builtin_amdgcn_wave_barrier();
+        { const uint32_t dt = PROF_NOW() - pui; pu_max = dt > pu_max ? dt : pu_max; pu_it += (min(pairs, p_lo + UNIT_PAIRS) - p_lo + 63u) / 64u; }
     }
+    const uint32_t pu2 = PROF_NOW();
+#ifdef ESIM_PROFILE_UNITS
+    PROF_PUT(d, 0, pu0); PROF_PUT(d, 1, pu1); PROF_PUT(d, 2, pu2); PROF_PUT(d, 4, pu_n); PROF_PUT(d, 5, pu_max); PROF_PUT(d, 7, pu_it);
+#endif
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
     for (uint32_t q = blockIdx.x; q < n_pairs; q += gridDim.x) {
         const uint32_t code = d.route_pairs_big[q], r = code >> 7, j = code & 127u;

@@ -7,7 +7,8 @@ names = ["t", "chunk_ok", "chunk_parallel", "chunk_pairs", "n_items", "items_per
 pop = Population.synthetic(sys.argv[1] if len(sys.argv) > 1 else "uk64m")
 sim = Simulator(pop, _lib.default_params(max_steps=5000))
 out = (C.c_uint32 * 16)()
-for target in (96, 960, 1920, 2880, 3840, 4800, 4992):
+targets = list(range(96, 96 * 13, 96)) + [1920, 2880, 3840, 4800, 4896, 4992]
+for target in targets:
     n = target - sim._steps
     t0 = time.perf_counter(); sim.run(n); dt = time.perf_counter() - t0
     _lib.check(sim.lib.esim_debug_counters(sim._ctx, out), sim._ctx)
