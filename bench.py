@@ -118,17 +118,17 @@ def main():
         value = n_total * steps / elapsed
         # One time step = one pass of the hot path.  While no vaccination programme runs, steps are processed in
         # chunks of <= 96 whose inputs are known ahead: normally ALL steps of a chunk are
-        # drawn by one pass of eight kernels (k_future, k_decide, k_chunk_marks, k_chunk_draw, k_chunk_units,
-        # k_chunk_count, k_chunk_finish, k_chunk_scatter; a burst of chunks is bracketed by one HIP event pair on the
-        # context's stream); when a chunk's marks do not fit the hash map it runs as one k_pipe launch per step
-        # (sampled event pairs).  Steps that can vaccinate run sequentially:
+        # drawn by one pass of four to six kernels (k_chunk_marks, k_chunk_draw, k_chunk_units, k_chunk_books, and
+        # k_chunk_count / k_chunk_scatter while many are Infected; a burst of chunks is bracketed by one HIP event pair
+        # on the context's stream); when a chunk does not fit that form it runs as one k_pipe launch per step (sampled
+        # event pairs).  Steps that can vaccinate run sequentially:
         # k_small (persistent, timed per launch) or k_infected + k_expose + k_finish (sampled).  Together they
         # carry SURVEY.md 8(d)'s 26 algorithmic bytes per citizen-timestep.
         pipe_steps = kp["steps"]
         seq_steps = steps - pipe_steps - kc["steps"]
         big_steps = seq_steps - ks["steps"]
-        parts = {"time-parallel chunk pass (k_future, k_decide, k_chunk_marks, k_chunk_draw [longest], k_chunk_units, k_chunk_count, "
-                 "k_chunk_finish, k_chunk_scatter)": kc["chunk_ms"],
+        parts = {"time-parallel chunk pass (k_chunk_marks, k_chunk_draw, k_chunk_units, k_chunk_books [+ k_chunk_count, "
+                 "k_chunk_scatter while many are Infected])": kc["chunk_ms"],
                  "k_pipe": pipe_steps * kp["k_pipe_ms"], "k_small": ks["k_small_ms"],
                  "k_infected+k_expose+k_finish": big_steps * kt["multi_kernel_step_ms"]}
         step_ms = sum(parts.values()) / steps
@@ -166,7 +166,7 @@ def main():
                                  "covers up to 96 steps); algorithmic bytes = 26 B x citizens of the shard per time step. "
                                  "frac >> 1 because the pass never touches most of the model's bytes: only infected citizens "
                                  "and the members of the buildings they stand in are visited, and the remaining work is "
-                                 "bound by Philox's 32-bit multiplies, not by HBM (DESIGN.md sections 3 and 5)",
+                                 "bound by memory latency and kernel boundaries, not by HBM (DESIGN.md sections 3 and 5)",
                          "wall_algorithmic_GBs": ALGO_BYTES_PER_CITIZEN_STEP * n_total * steps / elapsed / 1e9},
             "final_record": {k: int(rec[k][-1]) for k in ("time_step", "susceptible", "exposed", "infected", "recovered", "vaccinated")},
         }

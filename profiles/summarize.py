@@ -51,18 +51,18 @@ def main():
         for k, v in traffic.items():
             short = k.split("(")[0]
             tj[short + "_bytes_per_launch"] = v["hbm_bytes_corrected"]
-        # HBM bytes of one time step: the three multi-workgroup kernels, weighted with the persistent kernel's
-        # launches (each k_small launch covers many steps; bench.py reports how many steps ran where)
-        multi = sum(v["hbm_bytes_corrected"] for k, v in traffic.items() if k.split("(")[0] in ("k_infected", "k_expose", "k_finish"))
-        tj["multi_kernel_step_bytes"] = multi
-        ks = [v for k, v in traffic.items() if k.split("(")[0] == "k_small"]
-        if ks and "--small-steps" in opts and "--multi-steps" in opts:
-            ns, nm = float(opts["--small-steps"]), float(opts["--multi-steps"])
-            small_total = ks[0]["hbm_bytes_corrected"] * ks[0]["launches"]
-            tj["k_small_total_bytes"] = small_total
-            tj["step_bytes_per_launch"] = (small_total + multi * nm) / (ns + nm)
-        else:
-            tj["step_bytes_per_launch"] = multi
+        # HBM bytes of one time step = bytes of all of the library's kernels over the profiled run / its time steps
+        # (--steps; a chunk pass covers up to 96 steps, so a per-kernel figure alone would not be per step)
+        ours = {k: v for k, v in traffic.items() if k.split("(")[0].startswith("k_")}
+        run_bytes = sum(v["hbm_bytes_corrected"] * v["launches"] for v in ours.values())
+        steps = float(opts.get("--steps", "5000"))
+        tj["run_bytes"] = run_bytes
+        tj["steps"] = steps
+        tj["step_bytes_per_launch"] = run_bytes / steps
+        chunks = max([v["launches"] for k, v in ours.items() if k.split("(")[0] == "k_chunk_marks"] + [0])
+        if chunks:
+            tj["chunk_passes"] = chunks
+            tj["chunk_pass_bytes"] = run_bytes / chunks
         with open(os.path.join(here, "traffic.json"), "w") as fh:
             json.dump(tj, fh, indent=1)
     with open(os.path.join(here, "%s_summary.json" % tag), "w") as fh:
