@@ -184,6 +184,26 @@ class Simulator:
             p(out["eligible"], C.c_uint8)), self._ctx)
         return out
 
+    # -- read access the reference's callers use ----------------------
+    def citizen_output_area_lookup(self):
+        """`Simulator::citizen_output_area_lookup` (simulator.rs:97, rebuilt at :200-231) as two arrays: the Output
+        Area every citizen currently stands in and its position in that area's `citizens` list.  The reference's
+        order inside an area depends on HashMap iteration; here it is ascending global index."""
+        st = self.download_state()
+        area = self.population.building_area[st["current_building"]].astype(np.uint32)
+        order = np.lexsort((np.arange(area.size), area))
+        local = np.empty(area.size, np.uint32)
+        start = np.concatenate([[0], np.cumsum(np.bincount(area, minlength=self.population.n_areas))])
+        local[order] = (np.arange(area.size) - start[area[order]]).astype(np.uint32)
+        return area, local
+
+    def infected_per_area(self):
+        """Infected citizens per Output Area where they currently stand (the heat-map `visualisation` draws from
+        `output_areas[..].citizens`, run/src/main.rs:246-259)."""
+        st = self.download_state()
+        area = self.population.building_area[st["current_building"]]
+        return np.bincount(area[st["status"] == _lib.INFECTED], minlength=self.population.n_areas)
+
     def enable_kernel_timing(self, stride):
         _lib.check(self.lib.esim_enable_kernel_timing(self._ctx, int(stride)), self._ctx)
 

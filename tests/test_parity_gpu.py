@@ -166,6 +166,24 @@ def test_stop_when_done_matches_reference_loop():
     sim.close()
 
 
+def test_read_access_for_visualisation():
+    # citizen_output_area_lookup / per-area infected counts rebuilt from the device state
+    pop = Population.synthetic("york", n_citizens=5000, n_areas=16, citizens_per_school=2500)
+    ep = _lib.default_params(**AGGRESSIVE)
+    sim = Simulator(pop, ep)
+    orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
+    sim.run(130); orc.run(130)                                   # hour 10: commuters are at work
+    ost = orc.state()
+    area, local = sim.citizen_output_area_lookup()
+    want_area = pop.building_area[ost["current_building"]]
+    assert (area == want_area).all() and (area != pop.building_area[pop.home_building]).any()
+    for a in (0, 7, 15):
+        members = np.nonzero(area == a)[0]
+        assert local[members].tolist() == list(range(len(members)))
+    assert sim.infected_per_area().tolist() == np.bincount(want_area[ost["status"] == _lib.INFECTED], minlength=16).tolist()
+    sim.close()
+
+
 def test_reset_reproduces_the_run():
     pop = Population.synthetic("york", n_citizens=5000, n_areas=16, citizens_per_school=2500)
     sim = Simulator(pop, _lib.default_params(**AGGRESSIVE))

@@ -99,6 +99,15 @@ def test_three_generated_shards_match_oracle():
     assert all("ok" in o for o in outs)
 
 
+def test_shards_without_any_infected_citizen_match_oracle():
+    # one seed in a world of three shards: two of them stay all-susceptible for the whole run (the normal case of the
+    # weak-scaling benchmark), their chunk passes have nothing to mark or draw
+    cfg = dict(backend="gloo", cuts="generated", spec=dict(n_citizens=15000, n_areas=48, citizens_per_school=2500, n_seeds=1),
+               params=dict(exposure_chance=0.004, seed=31, max_steps=500), steps=480, chunk=240)
+    outs = launch(3, cfg)
+    assert all("ok" in o for o in outs)
+
+
 def test_syn3m5_two_generated_shards_match_oracle():
     # BASELINE.json configs[3]: synthetic 3.5 M citizens, Output-Area sharded (here 2 ranks on the test GPU)
     cfg = dict(backend="gloo", cuts="generated", spec=dict(n_citizens=3457142, n_areas=15669, citizens_per_school=20600, n_seeds=10),
