@@ -1018,6 +1018,36 @@ extern "C" int esim_download_state(esim_ctx *ctx, uint8_t *status, uint16_t *tim
     return ESIM_OK;
 }
 
+extern "C" int esim_download_exposure_log(esim_ctx *ctx, uint32_t *citizen, uint32_t *step, uint8_t *on_bus, uint32_t cap, uint32_t *n_out)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded || !n_out) return fail(c, ESIM_ESTATE, "no population uploaded");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    Ctrl h;
+    HIP_TRY(c, hipMemcpy(&h, c->d.ctrl, sizeof h, hipMemcpyDeviceToHost));
+    const uint32_t t_done = c->host_t - 1u;                       // steps run so far
+    // log_off[TE_BIAS + s] = first entry of step s; the entries before step 1 are the seeds (simulator_builder.rs:1268-1287)
+    std::vector<uint32_t> off((size_t)t_done + 2u);
+    HIP_TRY(c, hipMemcpy(off.data(), c->d.log_off + TE_BIAS + 1u, sizeof(uint32_t) * (t_done + 1u), hipMemcpyDeviceToHost));
+    off[t_done + 1u] = h.log_len;
+    const uint32_t first = t_done ? off[0] : h.log_len, n = h.log_len - first;
+    *n_out = n;
+    if (n > cap || (n && (!citizen || !step || !on_bus))) return fail(c, ESIM_ERANGE, "esim_download_exposure_log: buffers too small (n_out holds the size needed)");
+    if (n == 0) return ESIM_OK;
+    uint32_t *d_c = nullptr; uint8_t *d_b = nullptr;
+    if (hipMalloc(&d_c, sizeof(uint32_t) * (size_t)n) != hipSuccess || hipMalloc(&d_b, n) != hipSuccess) { (void)hipFree(d_c); return fail(c, ESIM_ENOMEM, "esim_download_exposure_log: hipMalloc"); }
+    hipLaunchKernelGGL(k_export_log, dim3(grid_for(n, TPB, 2048)), dim3(TPB), 0, c->stream, c->d, first, n, d_c, d_b);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(citizen, d_c, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(on_bus, d_b, n, hipMemcpyDeviceToHost);
+    (void)hipFree(d_c); (void)hipFree(d_b);
+    if (e != hipSuccess) return fail(c, ESIM_ENODEVICE, std::string("esim_download_exposure_log: ") + hipGetErrorString(e));
+    for (uint32_t s = 1; s <= t_done; ++s)
+        for (uint32_t i = off[s - 1u]; i < off[s] && i - first < n; ++i) step[i - first] = s;
+    return ESIM_OK;
+}
+
 extern "C" int esim_enable_phase_timing(esim_ctx *ctx, int enable)
 {
     esim_ctx_impl *c = CTX(ctx);

@@ -1267,6 +1267,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     PROF_PUT(d, 0, pt0); PROF_PUT(d, 1, pt1); PROF_PUT(d, 2, pt2); PROF_PUT(d, 3, pt3);   // start, after preamble, after items, end
     PROF_PUT(d, 4, p_items); PROF_PUT(d, 5, p_item_max);
 #endif
+    (void)pt0; (void)pt1; (void)pt2; (void)pt3; (void)p_items; (void)p_item_max;
 }
 
 // The deferred units of long member lists, dealt to the wavefronts round-robin.
@@ -1345,6 +1346,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
 #ifdef ESIM_PROFILE_UNITS
     PROF_PUT(d, 0, pu0); PROF_PUT(d, 1, pu1); PROF_PUT(d, 2, pu2); PROF_PUT(d, 4, pu_n); PROF_PUT(d, 5, pu_max); PROF_PUT(d, 7, pu_it);
 #endif
+    (void)pu0; (void)pu1; (void)pu2; (void)pu_n; (void)pu_max; (void)pu_it;
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
     for (uint32_t q = blockIdx.x; q < n_pairs; q += gridDim.x) {
         const uint32_t code = d.route_pairs_big[q], r = code >> 7, j = code & 127u;
@@ -1822,6 +1824,17 @@ __global__ __launch_bounds__(FIN_TPB) void k_small(Dev d, uint32_t max_steps, ui
 }
 
 // Reference-shaped view of the state (esim_download_state).
+// Exposure log entries [first, first + n): the citizen and whether it was exposed on public transport (the bus bit of its
+// word outlives a later vaccination: vaccinate() keeps it).
+__global__ __launch_bounds__(TPB) void k_export_log(Dev d, uint32_t first, uint32_t n, uint32_t *citizen, uint8_t *on_bus)
+{
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+        const uint32_t c = d.log[first + i];
+        citizen[i] = c;
+        on_bus[i] = (d.cit[c] & CW_BUS_EXPOSED) ? 1 : 0;
+    }
+}
+
 __global__ __launch_bounds__(TPB) void k_decode_state(Dev d, uint8_t *status, uint16_t *timer, uint32_t *cur,
                                                       uint8_t *on_bus, uint8_t *elig)
 {

@@ -46,7 +46,7 @@ class StatisticsRecorder:
         self.exposures_all.extend((arr["exposures_building"].astype(np.int64) + arr["exposures_bus"]).tolist())
         self.memory_usage_entries.extend([_memory_usage()] * len(arr))
 
-    def dump_to_file(self, directory):
+    def dump_to_file(self, directory, per_output_area=None):
         """statistics.rs:113-150. `dump_to_file` calls next() first, which appends one all-zero
         trailing StatisticEntry (Q14) -- reproduced so downstream notebooks see the same shape."""
         os.makedirs(directory, exist_ok=True)          # fs::create_dir_all(directory), statistics.rs:116
@@ -54,7 +54,13 @@ class StatisticsRecorder:
         stats.append({"time_step": len(stats) + 1, "susceptible": 0, "exposed": 0, "infected": 0,
                       "recovered": 0, "vaccinated": 0})
         with open(directory + "exposures.json", "w") as f:
-            json.dump({"All": {"All": self.exposures_all}}, f)
+            # "All"/"All": exposures per time step.  (The reference overwrites this entry with every place's own series while
+            # it drains its map, statistics.rs:123-125, so what it leaves there is one arbitrary place's; the total is what
+            # the name says.)  "OutputArea": statistics.rs:127-130.
+            doc = {"All": {"All": self.exposures_all}}
+            if per_output_area is not None:
+                doc["OutputArea"] = per_output_area
+            json.dump(doc, f)
         with open(directory + "timings.json", "w") as f:
             json.dump(self.timer_entries, f)
         with open(directory + "memory.json", "w") as f:
@@ -76,12 +82,13 @@ def _memory_usage():
 class Simulator:
     """`Simulator::from(builder)` (simulator.rs:601-644): takes a built population."""
 
-    def __init__(self, population, params=None, area_code="synthetic", record_timings=False):
+    def __init__(self, population, params=None, area_code="synthetic", record_timings=False, area_codes=None):
         """record_timings: keep the reference's per-step function timers (statistics.rs:46-95,
         simulator.rs:137,140,143) -- GPU time of the three phases from HIP events; costs one
         synchronisation per step, so it is off unless asked for."""
         self.lib = _lib.load()
         self.area_code = area_code
+        self.area_codes = area_codes          # Output Area codes (reference_io), for the keys of exposures.json
         self.population = population
         self.params = params if params is not None else _lib.default_params()
         self.current_population = population.n_citizens
@@ -149,7 +156,7 @@ class Simulator:
                 if (done - 1) % DEBUG_ITERATION_PRINT == 0:
                     self._progress(start)
                     start = time.time()
-        self.statistics_recorder.dump_to_file(output_name)
+        self.statistics_recorder.dump_to_file(output_name, self.exposures_per_output_area(self.area_codes))
 
     def _progress(self, start):
         print("Completed %3d time steps, in: %6s seconds  Statistics: %s,   Memory usage: %s" % (
@@ -196,6 +203,63 @@ class Simulator:
         start = np.concatenate([[0], np.cumsum(np.bincount(area, minlength=self.population.n_areas))])
         local[order] = (np.arange(area.size) - start[area[order]]).astype(np.uint32)
         return area, local
+
+    def exposure_events(self):
+        """Every exposure so far as (citizen, time_step, on_bus) arrays, sorted by (time step, citizen): the
+        `add_exposure` calls of the run (statistics.rs:181-195)."""
+        n = C.c_uint32(0)
+        rc = self.lib.esim_download_exposure_log(self._ctx, None, None, None, 0, C.byref(n))
+        if rc not in (_lib.ESIM_OK, _lib.ESIM_ERANGE):
+            _lib.check(rc, self._ctx)
+        cit, step, bus = np.zeros(n.value, np.uint32), np.zeros(n.value, np.uint32), np.zeros(n.value, np.uint8)
+        if n.value:
+            p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+            _lib.check(self.lib.esim_download_exposure_log(self._ctx, p(cit, C.c_uint32), p(step, C.c_uint32), p(bus, C.c_uint8),
+                                                           n.value, C.byref(n)), self._ctx)
+        order = np.lexsort((cit, step))
+        return cit[order], step[order], bus[order]
+
+    def exposures_per_output_area(self, area_codes=None):
+        """What `exposures.json` holds under "OutputArea" (statistics.rs:119-136,156-171): per Output Area the number of
+        building exposures in every time step that had any, in time order.  An exposure in a building is credited to the
+        building's area (statistics.rs:186-190), which simulator.rs:324 makes the area the citizen stands in at that
+        step: its work building's from the "starts work" arm to the "goes home" arm of an unlocked day
+        (citizen.rs:176-206), its home's otherwise."""
+        cit, step, bus = self.exposure_events()
+        rec = self.records_so_far()
+        pop = self.population
+        # replay the schedule: the arm of step s runs iff no lockdown was in force, i.e. the record of step s - 1 has none
+        at_work = np.zeros(len(rec) + 1, bool)
+        cur = False
+        for s in range(1, len(rec) + 1):
+            if s == 1 or not rec["lockdown"][s - 2]:
+                h = s % 24
+                if h == self.params.start_hour:
+                    cur = True
+                elif h == self.params.end_hour:
+                    cur = False
+            at_work[s] = cur
+        b = bus == 0
+        c, s = cit[b], step[b]
+        has_work = pop.work_building[c] != pop.home_building[c]
+        where = np.where(at_work[s] & has_work, pop.work_building[c], pop.home_building[c])
+        area = pop.building_area[where]
+        out = {}
+        order = np.lexsort((s, area))
+        a_sorted, s_sorted = area[order], s[order]
+        if len(a_sorted):
+            key = a_sorted.astype(np.int64) * (len(rec) + 2) + s_sorted
+            uniq, counts = np.unique(key, return_counts=True)
+            for k, n in zip(uniq.tolist(), counts.tolist()):
+                a = k // (len(rec) + 2)
+                out.setdefault(area_codes[a] if area_codes else "OA%07d" % a, []).append(n)
+        return out
+
+    def records_so_far(self):
+        n = self._steps
+        buf = (_lib.StepResult * max(1, n))()
+        _lib.check(self.lib.esim_read_records(self._ctx, 1, n, buf), self._ctx)
+        return np.frombuffer(buf, dtype=RECORD_DTYPE, count=n).copy()
 
     def infected_per_area(self):
         """Infected citizens per Output Area where they currently stand (the heat-map `visualisation` draws from

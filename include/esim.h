@@ -196,6 +196,12 @@ int  esim_synchronize(esim_ctx *ctx);
  *   eligible member of Simulator::citizens_eligible_for_vaccine  (simulator.rs:97) */
 int  esim_download_state(esim_ctx *ctx, uint8_t *status, uint16_t *timer,
                          uint32_t *current_building, uint8_t *on_bus, uint8_t *eligible);
+/* Every exposure so far, in time order: the citizen (local index), the time step and whether it happened on public
+ * transport -- the calls of StatisticsRecorder::add_exposure (statistics.rs:181-195) that feed exposures.json's
+ * per-Output-Area series (statistics.rs:119-136).  A building exposure is credited to the Output Area the citizen stands
+ * in at that step (simulator.rs:324 only exposes members whose current area is the building's).  Order inside a time
+ * step is unspecified.  *n_out = number of exposures; ESIM_ERANGE (with *n_out set) when cap is too small. */
+int  esim_download_exposure_log(esim_ctx *ctx, uint32_t *citizen, uint32_t *step, uint8_t *on_bus, uint32_t cap, uint32_t *n_out);
 
 /* GPU time per phase since the last reset, seconds, in the reference's timer labels
  * (simulator.rs:137,140,143; statistics.rs:138-140):

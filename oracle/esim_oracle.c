@@ -113,6 +113,8 @@ typedef struct {
     uint32_t cur;          /* current_building_position, citizen.rs:127 */
     uint32_t room;         /* occupant_to_class, building.rs:341 */
     uint32_t school_draws; /* per-step count of room draws already taken (slot 16+j) */
+    uint32_t exp_step;     /* time step of the add_exposure call for this citizen (0: none), statistics.rs:181-195 */
+    uint32_t exp_area;     /* ... the Output Area credited (building exposures), or ORC_NO_ROOM for public transport */
     int32_t  inf_next;     /* link in the per-building infected list of this step */
 } citizen_t;
 
@@ -327,6 +329,7 @@ static int try_building_exposure(orc_sim *s, orc_record *rec, uint32_t b, uint32
     else slot = 1;
     if (citizen_expose(s, m, n, slot)) {
         rec->exposures_building++;
+        z->exp_step = s->time_step; z->exp_area = s->bld_area[b];   /* ID::Building -> its Output Area too, statistics.rs:186-190 */
         if (citizen_exposed_stat(rec)) return -1;          /* add_exposure, :356-358 */
         /* area.citizens_eligible_for_vaccine is always None (output_area.rs:113) => no removal, Q10 */
     }
@@ -421,6 +424,7 @@ int orc_step(orc_sim *s, orc_record *out)
                     uint32_t m = s->riders[k].id;
                     if (s->cit[m].status == ORC_S && citizen_expose(s, m, exposure_count, 2)) {
                         rec.exposures_bus++;
+                        s->cit[m].exp_step = s->time_step; s->cit[m].exp_area = ORC_NO_ROOM;   /* ID::PublicTransport */
                         if (citizen_exposed_stat(&rec)) err = -1;
                         if (s->have_eligible && s->cit[m].eligible) {   /* :447-449 */
                             s->cit[m].eligible = 0; s->eligible_count--;
@@ -503,6 +507,13 @@ int orc_run(orc_sim *s, uint32_t n, orc_record *out, int stop_when_done)
         if (stop_when_done && !out[k].disease_exists) { ++k; break; }
     }
     return (int)k;
+}
+
+/* The add_exposure calls so far (statistics.rs:181-195): per citizen the time step (0: never exposed by the simulation)
+ * and the Output Area credited, ORC_NO_ROOM for an exposure on public transport. */
+void orc_get_exposures(const orc_sim *s, uint32_t *step, uint32_t *area)
+{
+    for (uint32_t c = 0; c < s->n_cit; ++c) { step[c] = s->cit[c].exp_step; area[c] = s->cit[c].exp_area; }
 }
 
 void orc_get_state(const orc_sim *s, uint8_t *status, uint16_t *timer,

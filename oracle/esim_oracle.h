@@ -116,6 +116,10 @@ int      orc_run(orc_sim *s, uint32_t n, orc_record *out, int stop_when_done);
 void     orc_get_state(const orc_sim *s, uint8_t *status, uint16_t *timer,
                        uint8_t *at_work, uint8_t *bus, uint8_t *eligible);
 
+/* The add_exposure calls so far (statistics.rs:181-195), per citizen: time step (0 = none) and Output Area credited
+ * (ORC_NO_ROOM: public transport). */
+void     orc_get_exposures(const orc_sim *s, uint32_t *step, uint32_t *area);
+
 /* primitives exposed so tests can pin them */
 void     orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double   orc_binomial(double probability, uint8_t n);                 /* citizen.rs:47-49 */

@@ -184,6 +184,34 @@ def test_read_access_for_visualisation():
     sim.close()
 
 
+def test_exposure_log_and_per_output_area_series_match_the_oracle():
+    # every add_exposure call of the run (statistics.rs:181-195): who, when, on a bus or in a building of which Output Area --
+    # through chunks, the vaccination programme (sequential steps; vaccinated citizens keep their entry) and a lockdown
+    pop = Population.synthetic("york", n_citizens=6000, n_areas=20, citizens_per_school=3000, n_seeds=12, p_public_transport=0.4)
+    ep = _lib.default_params(**AGGRESSIVE)
+    for level in (2, 0):
+        sim = Simulator(pop, ep)
+        sim.set_pipeline(level)
+        orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
+        sim.run(420); orc.run(420)
+        o_step, o_area = orc.exposures()
+        cit, step, bus = sim.exposure_events()
+        want = np.nonzero(o_step)[0]
+        assert len(cit) == len(want) > 500
+        order = np.lexsort((want, o_step[want]))
+        assert (cit == want[order]).all() and (step == o_step[want][order]).all()
+        assert (bus == (o_area[want][order] == 0xFFFFFFFF)).all() and bus.any() and not bus.all()
+        per_area = sim.exposures_per_output_area()
+        ref = {}
+        b = o_area != 0xFFFFFFFF
+        for a in np.unique(o_area[b & (o_step > 0)]):
+            steps = o_step[b & (o_step > 0) & (o_area == a)]
+            ref["OA%07d" % a] = np.unique(steps, return_counts=True)[1].tolist()
+        assert per_area == ref
+        assert sum(sum(v) for v in per_area.values()) == int((bus == 0).sum())
+        sim.close()
+
+
 def test_reset_reproduces_the_run():
     pop = Population.synthetic("york", n_citizens=5000, n_areas=16, citizens_per_school=2500)
     sim = Simulator(pop, _lib.default_params(**AGGRESSIVE))
@@ -230,6 +258,7 @@ def test_simulate_writes_the_reference_output_files(tmp_path):
     assert all(t["total"] > 0 for t in timings)
     exposures = json.load(open(out + "exposures.json"))
     assert exposures["All"]["All"] == [int(a) + int(b) for a, b in zip(orc["exposures_building"], orc["exposures_bus"])]
+    assert sum(sum(v) for v in exposures["OutputArea"].values()) == int(orc["exposures_building"].sum())
     assert len(json.load(open(out + "memory.json"))) == 60
     sim.close()
 
