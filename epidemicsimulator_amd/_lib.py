@@ -85,7 +85,7 @@ SYMBOLS = [
     "esim_exchange_buffer", "esim_future_infected", "esim_run_free", "esim_free_begin", "esim_free_enqueue", "esim_free_collect", "esim_set_pipeline", "esim_chunk_timing", "esim_pipeline_timing",
     "esim_read_records", "esim_stream", "esim_set_stream",
     "esim_set_exchange_buffer", "esim_synchronize",
-    "esim_download_state", "esim_download_exposure_log", "esim_enable_phase_timing", "esim_phase_timings",
+    "esim_download_state", "esim_download_exposure_log", "esim_checkpoint_size", "esim_checkpoint_save", "esim_checkpoint_restore", "esim_enable_phase_timing", "esim_phase_timings",
     "esim_enable_kernel_timing", "esim_kernel_timings", "esim_set_small_step_limit", "esim_small_kernel_timing", "esim_debug_counters",
     "esim_last_error", "esim_destroy",
     "esim_threshold_lut", "esim_synth_preset", "esim_synth_create", "esim_synth_create_shard", "esim_synth_free",
@@ -132,6 +132,9 @@ def load():
         "esim_synchronize": (C.c_int, [vp]),
         "esim_download_state": (C.c_int, [vp, _u8p, _u16p, _u32p, _u8p, _u8p]),
         "esim_download_exposure_log": (C.c_int, [vp, _u32p, _u32p, _u8p, C.c_uint32, _u32p]),
+        "esim_checkpoint_size": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+        "esim_checkpoint_save": (C.c_int, [vp, vp, C.c_size_t]),
+        "esim_checkpoint_restore": (C.c_int, [vp, vp, C.c_size_t]),
         "esim_enable_phase_timing": (C.c_int, [vp, C.c_int]),
         "esim_phase_timings": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "esim_enable_kernel_timing": (C.c_int, [vp, C.c_int]),

@@ -1048,6 +1048,116 @@ extern "C" int esim_download_exposure_log(esim_ctx *ctx, uint32_t *citizen, uint
     return ESIM_OK;
 }
 
+// ---- checkpoint / restore: everything a step reads that is not part of the uploaded population ----------------------
+namespace {
+struct CkptHeader {
+    uint32_t magic, version, n, n_global, id_base, max_steps, host_t, log_len;
+    uint32_t exposed_time, infected_time, vaccination_rate, bus_capacity, start_hour, end_hour, ctrl_bytes, reserved;
+    uint64_t seed;
+    double thresholds[6];
+};
+const uint32_t CKPT_MAGIC = 0x4D495345u /* "ESIM" */, CKPT_VERSION = 1u;
+
+void ckpt_header(const esim_ctx_impl *c, const Ctrl &h, CkptHeader *o)
+{
+    std::memset(o, 0, sizeof *o);
+    o->magic = CKPT_MAGIC; o->version = CKPT_VERSION; o->n = c->d.n; o->n_global = c->d.n_global; o->id_base = c->d.id_base;
+    o->max_steps = c->P.max_steps; o->host_t = c->host_t; o->log_len = h.log_len;
+    o->exposed_time = c->P.exposed_time; o->infected_time = c->P.infected_time; o->vaccination_rate = c->P.vaccination_rate;
+    o->bus_capacity = c->P.bus_capacity; o->start_hour = c->P.start_hour; o->end_hour = c->P.end_hour; o->ctrl_bytes = (uint32_t)sizeof(Ctrl);
+    o->seed = c->P.seed;
+    const double th[6] = { c->P.exposure_chance, c->P.mask_effectiveness, c->P.lockdown_threshold, c->P.vaccination_threshold,
+                           c->P.mask_pt_threshold, c->P.mask_everywhere_threshold };
+    std::memcpy(o->thresholds, th, sizeof th);
+}
+
+size_t ckpt_bytes(const CkptHeader &k)
+{
+    return sizeof(CkptHeader) + k.ctrl_bytes + sizeof(uint32_t) * ((size_t)TE_SLOTS + TE_SLOTS + 1 + k.n + k.log_len + 2u * ((size_t)k.host_t + 1u)) +
+           sizeof(esim_step_result) * (size_t)k.host_t;
+}
+}  // namespace
+
+extern "C" int esim_checkpoint_size(esim_ctx *ctx, size_t *bytes)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded || !bytes) return fail(c, ESIM_ESTATE, "no population uploaded");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    Ctrl h;
+    HIP_TRY(c, hipMemcpy(&h, c->d.ctrl, sizeof h, hipMemcpyDeviceToHost));
+    CkptHeader k;
+    ckpt_header(c, h, &k);
+    *bytes = ckpt_bytes(k);
+    return ESIM_OK;
+}
+
+extern "C" int esim_checkpoint_save(esim_ctx *ctx, void *buf, size_t cap)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded || !buf) return fail(c, ESIM_ESTATE, "no population uploaded");
+    if (c->free_limit) return fail(c, ESIM_ESTATE, "esim_checkpoint_save: a burst of decoupled chunks is open");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const Dev &d = c->d;
+    Ctrl h;
+    HIP_TRY(c, hipMemcpy(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost));
+    if (h.error) return fail(c, -(int)h.error, "esim_checkpoint_save: the context is in a device-side error state");
+    CkptHeader k;
+    ckpt_header(c, h, &k);
+    if (cap < ckpt_bytes(k)) return fail(c, ESIM_ERANGE, "esim_checkpoint_save: buffer smaller than esim_checkpoint_size");
+    uint8_t *p = (uint8_t *)buf;
+    std::memcpy(p, &k, sizeof k); p += sizeof k;
+    std::memcpy(p, &h, sizeof h); p += sizeof h;
+    auto pull = [&](const void *src, size_t bytes) -> int { if (bytes) HIP_TRY(c, hipMemcpy(p, src, bytes, hipMemcpyDeviceToHost)); p += bytes; return ESIM_OK; };
+    int rc;
+    if ((rc = pull(d.hist, sizeof(uint32_t) * TE_SLOTS))) return rc;
+    if ((rc = pull(d.log_off, sizeof(uint32_t) * (TE_SLOTS + 1)))) return rc;
+    if ((rc = pull(d.cit, sizeof(uint32_t) * (size_t)d.n))) return rc;
+    if ((rc = pull(d.log, sizeof(uint32_t) * (size_t)h.log_len))) return rc;
+    if ((rc = pull(d.exp_step, sizeof(uint32_t) * 2u * ((size_t)c->host_t + 1u)))) return rc;
+    if ((rc = pull(d.records, sizeof(esim_step_result) * (size_t)c->host_t))) return rc;
+    return ESIM_OK;
+}
+
+extern "C" int esim_checkpoint_restore(esim_ctx *ctx, const void *buf, size_t bytes)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded || !buf) return fail(c, ESIM_ESTATE, "no population uploaded");
+    if (bytes < sizeof(CkptHeader)) return fail(c, ESIM_EINVAL, "esim_checkpoint_restore: not a checkpoint");
+    CkptHeader k, mine;
+    std::memcpy(&k, buf, sizeof k);
+    Ctrl zero;
+    std::memset(&zero, 0, sizeof zero);
+    ckpt_header(c, zero, &mine);
+    if (k.magic != CKPT_MAGIC || k.version != CKPT_VERSION || k.ctrl_bytes != sizeof(Ctrl)) return fail(c, ESIM_EINVAL, "esim_checkpoint_restore: not a checkpoint of this library version");
+    if (k.n != mine.n || k.n_global != mine.n_global || k.id_base != mine.id_base || k.seed != mine.seed || k.exposed_time != mine.exposed_time ||
+        k.infected_time != mine.infected_time || k.vaccination_rate != mine.vaccination_rate || k.bus_capacity != mine.bus_capacity ||
+        k.start_hour != mine.start_hour || k.end_hour != mine.end_hour || std::memcmp(k.thresholds, mine.thresholds, sizeof k.thresholds) != 0)
+        return fail(c, ESIM_EINVAL, "esim_checkpoint_restore: the checkpoint was taken with another population, shard or parameter set");
+    if (k.host_t == 0 || k.host_t - 1u > c->P.max_steps || k.log_len > k.n) return fail(c, ESIM_EINVAL, "esim_checkpoint_restore: steps beyond this context's max_steps");
+    if (bytes < ckpt_bytes(k)) return fail(c, ESIM_EINVAL, "esim_checkpoint_restore: truncated checkpoint");
+    int rc = esim_reset(ctx);                                     // clean marks, chunk tables are clean between calls anyway
+    if (rc) return rc;
+    const Dev &d = c->d;
+    const uint8_t *p = (const uint8_t *)buf + sizeof k;
+    Ctrl h;
+    std::memcpy(&h, p, sizeof h); p += sizeof h;
+    // marks of the last step are only ever cleared, never read, by the step after it: start without them
+    for (uint32_t z = 0; z < MARK_SLOTS; ++z) { h.n_touched_bld[z] = 0; h.n_touched_room[z] = 0; h.n_touched_route[z] = 0; h.n_touched_route_big[z] = 0; }
+    auto push = [&](void *dst, size_t nb) -> int { if (nb) HIP_TRY(c, hipMemcpy(dst, p, nb, hipMemcpyHostToDevice)); p += nb; return ESIM_OK; };
+    if ((rc = push(d.hist, sizeof(uint32_t) * TE_SLOTS))) return rc;
+    if ((rc = push(d.log_off, sizeof(uint32_t) * (TE_SLOTS + 1)))) return rc;
+    if ((rc = push(d.cit, sizeof(uint32_t) * (size_t)d.n))) return rc;
+    if ((rc = push(d.log, sizeof(uint32_t) * (size_t)k.log_len))) return rc;
+    if ((rc = push(d.exp_step, sizeof(uint32_t) * 2u * ((size_t)k.host_t + 1u)))) return rc;
+    if ((rc = push(d.records, sizeof(esim_step_result) * (size_t)k.host_t))) return rc;
+    HIP_TRY(c, hipMemcpy(d.ctrl, &h, sizeof h, hipMemcpyHostToDevice));
+    c->host_t = k.host_t;
+    c->last_chunk_pairs = h.chunk_pairs;
+    return ESIM_OK;
+}
+
 extern "C" int esim_enable_phase_timing(esim_ctx *ctx, int enable)
 {
     esim_ctx_impl *c = CTX(ctx);

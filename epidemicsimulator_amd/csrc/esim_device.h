@@ -73,8 +73,8 @@ struct Ctrl {
     uint32_t chunk_pairs;       // log entries that are Infected in some step of the chunk, this shard (k_future)
     uint32_t n_items;           // marked (building | room | route, step) entries of the chunk
     uint32_t n_newexp;          // citizens exposed in the chunk
-    uint32_t n_units, unit_next; // deferred units of long member lists (k_chunk_units)
-    uint32_t n_route_pairs;     // (route item, bus step) pairs with an Infected rider, routes of <= 64 riders
+    uint32_t n_units, unit_next; // deferred units of the last chunk (diagnostics; the queues' own counters live in Dev::hot)
+    uint32_t n_route_pairs;     // (unused: those pairs are counted per wavefront, Dev::pair_cnt)
     uint32_t n_route_pairs_big; // ... routes of more riders
     uint32_t chunk_done;        // the books of the last time-parallel chunk were written (k_chunk_books)
     uint32_t prev_t0, prev_n_items, prev_per_wave; // that chunk, for k_chunk_scatter

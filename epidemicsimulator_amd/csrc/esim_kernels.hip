@@ -113,21 +113,6 @@ __device__ __forceinline__ void append(uint32_t *list, uint32_t *len, uint32_t v
     list[atomicAdd(len, 1u)] = v;
 }
 
-// The same for all lanes of a wavefront that are active here and have `pred` set, with ONE atomic on the shared
-// length (atomics on a single address are served one at a time, ~10 ns each: thousands of single appends per pass
-// would be its critical path).  `len` must be the same for all of them.
-__device__ __forceinline__ void append_wave(uint32_t *list, uint32_t *len, uint32_t v, bool pred)
-{
-    const unsigned long long m = __ballot(pred);
-    if (!pred) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(len, (uint32_t)__popcll(m));
-    base = __shfl(base, leader, 64);
-    list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
-}
-
 // Diagnostics build (make prof): every wavefront of the chunk-pass kernels stores its timers in its own row of
 // d.prof_buf -- no atomics, so the measurement does not serialise the kernel it measures.
 #ifdef ESIM_WAVE_PROFILE
@@ -718,11 +703,13 @@ __global__ __launch_bounds__(TPB) void k_pipe(Dev d, uint32_t t, uint32_t j, uin
 // step a building exposure precedes a bus exposure (simulator.rs:268-401).  With the exposure step in the top
 // bits of the citizen word and the bus bit right below, that is one atomicMin per successful draw -- so all
 // steps of the chunk are drawn in ONE pass.
-//   k_chunk_marks  an item per building / room / route that somebody Infected stands in during the chunk, with
-//                  the number of Infected standing there in each of its steps (generate_exposures)
-//   k_chunk_draw   the (member, marked step) pairs of every item, densely over the lanes (apply_exposures)
-//   k_chunk_units  the same for member lists too long for one wavefront
-//   k_chunk_count, k_batch_finish, k_chunk_scatter   exposure counts, books, log entries
+//   k_chunk_marks  an item per building / room / route that somebody Infected stands in during the chunk, and per item the
+//                  stretches of steps in which each of them stands there (generate_exposures)
+//   k_chunk_draw   the (member, marked step) pairs of every item, densely over the lanes (apply_exposures); long member
+//                  lists are cut into units
+//   k_chunk_units  the units, dealt evenly; routes of more than 64 riders
+//   k_chunk_books  exposure counts, records, log entries, clean-up, the next chunk's decisions
+//                  (k_chunk_count / k_chunk_scatter: its two wide parts as kernels of their own while many are Infected)
 __device__ __forceinline__ uint32_t hash64(unsigned long long k)
 {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;

@@ -261,6 +261,35 @@ class Simulator:
         _lib.check(self.lib.esim_read_records(self._ctx, 1, n, buf), self._ctx)
         return np.frombuffer(buf, dtype=RECORD_DTYPE, count=n).copy()
 
+    # -- checkpoint / resume --------------------------------------------------------------
+    def save_checkpoint(self, path):
+        """Everything needed to continue this run later, bit for bit (esim_checkpoint_save), as one file."""
+        size = C.c_size_t(0)
+        _lib.check(self.lib.esim_checkpoint_size(self._ctx, C.byref(size)), self._ctx)
+        buf = np.empty(size.value, np.uint8)
+        _lib.check(self.lib.esim_checkpoint_save(self._ctx, buf.ctypes.data_as(C.c_void_p), size.value), self._ctx)
+        with open(path, "wb") as f:
+            buf.tofile(f)
+
+    def load_checkpoint(self, path):
+        """Continue a run saved by `save_checkpoint` with the same population and parameters."""
+        buf = np.fromfile(path, np.uint8)
+        _lib.check(self.lib.esim_checkpoint_restore(self._ctx, buf.ctypes.data_as(C.c_void_p), buf.size), self._ctx)
+        # the number of steps done is in the control block; find it through the records
+        probe = _lib.StepResult()
+        lo, hi = 0, int(self.params.max_steps)
+        while lo < hi:                                           # records are written in order: last one with a time step
+            mid = (lo + hi + 1) // 2
+            _lib.check(self.lib.esim_read_records(self._ctx, mid, 1, C.byref(probe)), self._ctx)
+            if probe.time_step == mid:
+                lo = mid
+            else:
+                hi = mid - 1
+        self._steps = lo
+        self.statistics_recorder = StatisticsRecorder()
+        if lo:
+            self.statistics_recorder.push_block(self.records_so_far())
+
     def infected_per_area(self):
         """Infected citizens per Output Area where they currently stand (the heat-map `visualisation` draws from
         `output_areas[..].citizens`, run/src/main.rs:246-259)."""

@@ -202,6 +202,14 @@ int  esim_download_state(esim_ctx *ctx, uint8_t *status, uint16_t *timer,
  * in at that step (simulator.rs:324 only exposes members whose current area is the building's).  Order inside a time
  * step is unspecified.  *n_out = number of exposures; ESIM_ERANGE (with *n_out set) when cap is too small. */
 int  esim_download_exposure_log(esim_ctx *ctx, uint32_t *citizen, uint32_t *step, uint8_t *on_bus, uint32_t cap, uint32_t *n_out);
+/* Checkpoint / resume (the reference has none for the simulation state): everything a step reads that is
+ * not part of the uploaded population -- the citizen words, the census histogram, the exposure log, the control block,
+ * the records so far.  Restore goes into a context that holds the SAME population (or shard) and parameters; the run
+ * continues bit for bit as if it had not been interrupted.  Between calls, i.e. never inside esim_step_begin..finish or
+ * an open burst. */
+int  esim_checkpoint_size(esim_ctx *ctx, size_t *bytes);
+int  esim_checkpoint_save(esim_ctx *ctx, void *buf, size_t cap);
+int  esim_checkpoint_restore(esim_ctx *ctx, const void *buf, size_t bytes);
 
 /* GPU time per phase since the last reset, seconds, in the reference's timer labels
  * (simulator.rs:137,140,143; statistics.rs:138-140):

@@ -212,6 +212,35 @@ def test_exposure_log_and_per_output_area_series_match_the_oracle():
         sim.close()
 
 
+def test_checkpoint_resume_continues_bit_for_bit(tmp_path):
+    # save in the middle of the vaccination programme, continue in a NEW context: records, state and exposure log as if
+    # the run had never stopped; a checkpoint of another population or seed is refused
+    pop = Population.synthetic("york", n_citizens=6000, n_areas=20, citizens_per_school=3000, n_seeds=12)
+    ep = _lib.default_params(**AGGRESSIVE)
+    whole = Simulator(pop, ep)
+    ref = whole.run(500)
+    for at in (130, 330):                                        # inside a chunked stretch / inside the vaccination programme
+        a = Simulator(pop, ep)
+        first = a.run(at)
+        path = str(tmp_path / ("ckpt%d.bin" % at))
+        a.save_checkpoint(path)
+        a.close()
+        b = Simulator(pop, ep)
+        b.load_checkpoint(path)
+        assert b._steps == at and len(b.statistics_recorder.global_stats) == at
+        rest = b.run(500 - at)
+        assert_same_records(np.concatenate([first, rest]), ref)
+        sa, sb = whole.download_state(), b.download_state()
+        assert all((sa[k] == sb[k]).all() for k in sa)
+        ea, eb = whole.exposure_events(), b.exposure_events()
+        assert all((x == y).all() for x, y in zip(ea, eb))
+        b.close()
+    other = Simulator(pop, _lib.default_params(**dict(AGGRESSIVE, seed=78)))
+    with pytest.raises(_lib.EsimError, match="another population"):
+        other.load_checkpoint(path)
+    other.close(); whole.close()
+
+
 def test_reset_reproduces_the_run():
     pop = Population.synthetic("york", n_citizens=5000, n_areas=16, citizens_per_school=2500)
     sim = Simulator(pop, _lib.default_params(**AGGRESSIVE))
