@@ -616,7 +616,8 @@ int run_sequential(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, ui
 // then_next: also prepare the chunk after it (census ahead + decisions: what k_future and k_decide do), for steps up to limit_t.
 // While few citizens are Infected the books, the log scatter, the clean-up and that preparation are ONE single-workgroup
 // kernel (a kernel boundary costs more than these steps); with many, the scatter and clean-up need the whole chip.
-void enqueue_parallel_chunk(esim_ctx_impl *c, bool then_next, uint32_t limit_t)
+// then_next: 0 nothing, 1 census ahead + decisions of the next chunk, 2 census ahead only.
+void enqueue_parallel_chunk(esim_ctx_impl *c, int then_next, uint32_t limit_t)
 {
     Dev &d = c->d;
     const bool small = c->last_chunk_pairs < 1024u;
@@ -624,7 +625,7 @@ void enqueue_parallel_chunk(esim_ctx_impl *c, bool then_next, uint32_t limit_t)
     hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     if (!small) hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);
-    hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, small ? 1 : 0, then_next ? 1 : 0, (uint32_t)c->xf_n, limit_t);
+    hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, small ? 1 : 0, then_next, (uint32_t)c->xf_n, limit_t);
     if (!small) hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d);
 }
 
@@ -648,7 +649,7 @@ int run_chunk(esim_ctx_impl *c, uint32_t n_ahead, uint32_t *executed, Ctrl *stat
         // every step of the chunk in one pass: marks of all steps, draws of all (item, step) pairs, then the books
         const bool tk = c->kernel_timing;
         if (tk) { if (!c->cev[0]) { (void)hipEventCreate(&c->cev[0]); (void)hipEventCreate(&c->cev[1]); } HIP_TRY(c, hipEventRecord(c->cev[0], c->stream)); }
-        enqueue_parallel_chunk(c, false, 0u);
+        enqueue_parallel_chunk(c, 0, 0u);
         if (tk) { HIP_TRY(c, hipEventRecord(c->cev[1], c->stream)); HIP_TRY(c, hipEventSynchronize(c->cev[1])); float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->cev[0], c->cev[1])); c->chunk_ms += ms; }
         HIP_TRY(c, hipGetLastError());
         c->chunk_steps += n; c->chunk_count++;
@@ -698,7 +699,7 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             if (tk) { if (!c->cev[0]) { (void)hipEventCreate(&c->cev[0]); (void)hipEventCreate(&c->cev[1]); } HIP_TRY(c, hipEventRecord(c->cev[0], c->stream)); }
             hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
             hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1);
-            for (uint32_t g = 0; g < bursts; ++g) enqueue_parallel_chunk(c, g + 1u < bursts, limit_t);
+            for (uint32_t g = 0; g < bursts; ++g) enqueue_parallel_chunk(c, g + 1u < bursts ? 1 : 0, limit_t);
             if (tk) HIP_TRY(c, hipEventRecord(c->cev[1], c->stream));
             Ctrl h;
             HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -817,7 +818,7 @@ extern "C" int esim_free_enqueue(esim_ctx *ctx)
         for (int i = 0; i < 2 && tk; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) tk = false; else c->fev.push_back(e); }
     if (tk) HIP_TRY(c, hipEventRecord(c->fev[c->fev_used], c->stream));
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d, (uint32_t)c->xf_n, c->free_limit, 1);
-    enqueue_parallel_chunk(c, false, 0u);
+    enqueue_parallel_chunk(c, 2, c->free_limit);                  // leaves the census ahead of the NEXT chunk in buffer F
     if (tk) { HIP_TRY(c, hipEventRecord(c->fev[c->fev_used + 1], c->stream)); c->fev_used += 2; }
     HIP_TRY(c, hipGetLastError());
     return ESIM_OK;

@@ -1515,7 +1515,13 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
     __shared__ uint32_t wtmp[FIN_TPB / 64];
     Ctrl *ctrl = d.ctrl;
     const uint32_t tid = threadIdx.x;
-    if (!ctrl->chunk_parallel || ctrl->chunk_ok == 0u) { if (tid == 0) ctrl->chunk_done = 0u; return; }
+    if (!ctrl->chunk_parallel || ctrl->chunk_ok == 0u) {
+        if (tid == 0) ctrl->chunk_done = 0u;
+        // a sharded burst all-reduces buffer F in place before every chunk: it must hold THIS shard's census again, whether
+        // or not the chunk ran
+        if (do_next == 2) future_body(d, max_ahead, limit_t, win, wtmp);
+        return;
+    }
     const uint32_t t0 = ctrl->chunk_t0, n = ctrl->chunk_ok;
     const uint32_t n_items = min(ld(&ctrl->n_items), d.items_cap);
     if (tid < 2u * FREE_MAX) e_cnt[tid] = 0u;
@@ -1593,10 +1599,11 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
         }
     }
     if (do_next) {
+        // 1: the next chunk's census ahead and decisions; 2: the census ahead only (sharded runs all-reduce it before deciding)
         __syncthreads();
         future_body(d, max_ahead, limit_t, win, wtmp);
         __syncthreads();
-        if (tid < 64u) decide_body(d, max_ahead, limit_t, 1);
+        if (do_next == 1 && tid < 64u) decide_body(d, max_ahead, limit_t, 1);
     }
 }
 

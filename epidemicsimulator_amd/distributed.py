@@ -121,14 +121,14 @@ class ShardedSimulator:
         with torch.cuda.stream(self.stream):
             while done < n_steps:
                 if self.mode_free and self.burst_max > 0 and self._sync_left == 0:
-                    # several whole chunks in flight: { census ahead; all-reduce; chunk } x burst, one wait at the end.
+                    # several whole chunks in flight: census ahead, then { all-reduce; chunk + next census ahead } x burst, one wait at the end.
                     # A chunk that cannot run this way is a no-op on every rank; the chunk-by-chunk form below then
                     # takes it and the burst length starts again from one.
                     want = n_steps - done
                     chunks = min(-(-want // self.free_batch), self._burst)
                     _lib.check(lib.esim_free_begin(ctx, want), ctx)
-                    for _ in range(chunks):
-                        _lib.check(lib.esim_future_infected(ctx), ctx)
+                    _lib.check(lib.esim_future_infected(ctx), ctx)
+                    for _ in range(chunks):                       # (a chunk's last kernel leaves the next census ahead in F)
                         dist.all_reduce(self.xbuf[2], group=self.group)
                         _lib.check(lib.esim_free_enqueue(ctx), ctx)
                     got = C.c_uint32(0)

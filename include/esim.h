@@ -158,10 +158,11 @@ int  esim_exchange_buffer(esim_ctx *ctx, int which /* 0 = A, 1 = B, 2 = F */, vo
  * Buffer F holds n + 1 words: the census of the next n steps and one word counting the shards whose chunk does
  * not fit the one-pass form below (after the all-reduce every shard therefore takes the same form).
  * Bursts: esim_run_free waits for the device once per chunk.  To keep several chunks in flight the caller
- * opens a burst with esim_free_begin(k) (k = steps it may cover), repeats { esim_future_infected; all-reduce F;
- * esim_free_enqueue } as often as it likes -- each round enqueues one whole chunk, which is a no-op on EVERY
- * shard when it cannot run in the one-pass form or would reach the step that starts vaccinating -- and calls
- * esim_free_collect(&done) once: done = steps the burst advanced (the same on all shards).
+ * opens a burst with esim_free_begin(k) (k = steps it may cover), calls esim_future_infected once and then repeats
+ * { all-reduce F; esim_free_enqueue } as often as it likes -- each round enqueues one whole chunk, which is a no-op on
+ * EVERY shard when it cannot run in the one-pass form or would reach the step that starts vaccinating, and which ends by
+ * writing the census ahead of the chunk after it into F -- and calls esim_free_collect(&done) once: done = steps the
+ * burst advanced (the same on all shards).
  * esim_set_pipeline(ctx, level): 0 = sequential steps only; 1 = chunks run as one kernel per step (k_pipe);
  * 2 (default) = additionally, when the chunk's marks fit the hash map, ALL steps of a chunk are drawn in one
  * pass (a citizen's exposure step is the earliest step at which any of its draws succeeds -- one atomicMin on
