@@ -1,0 +1,1119 @@
+// esim_kernels_chunk.h -- chunks of up to 96 time steps: the census ahead and the decisions of a chunk (k_future, k_decide),
+// the one-pass form (k_chunk_marks, k_chunk_draw, k_chunk_units, k_chunk_books [+ k_chunk_count, k_chunk_scatter]) and the
+// books of a chunk that ran step by step (k_batch_finish).
+#pragma once
+// ------------------------------------------------------------------------------- chunk set-up
+// A citizen exposed in step t is Infected no earlier than step t + exposed_time + 1 (disease.rs:47-71), so the
+// Infected census of the next <= exposed_time + 1 steps is already fixed -- as long as nobody is vaccinated.
+// k_future writes that vector for this shard (sharded runs SUM-all-reduce it); k_decide then runs the
+// intervention state machine (interventions.rs:110-184 needs nothing but the infected fraction) and the
+// schedule (citizen.rs:176-206) over the chunk and stops in front of the step that would start vaccinating.
+// Inclusive prefix sum over BF_WIN values in shared memory, by a workgroup of FIN_TPB = BF_WIN threads.
+#define BF_WIN 1024
+__device__ __forceinline__ void block_scan_1024(uint32_t *v, uint32_t *wtmp)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    uint32_t x = v[tid];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= (uint32_t)o) x += y; }
+    if (lane == 63u) wtmp[wv] = x;
+    __syncthreads();
+    if (tid == 0) { uint32_t a = 0; for (uint32_t w = 0; w < FIN_TPB / 64; ++w) { const uint32_t y = wtmp[w]; wtmp[w] = a; a += y; } }
+    __syncthreads();
+    v[tid] = x + wtmp[wv];
+    __syncthreads();
+}
+
+// (Control block, histogram and census vector are read past the caches: in k_chunk_books the same workgroup has just
+// written them.)
+__device__ __forceinline__ void future_body(const Dev &d, uint32_t max_ahead, uint32_t limit_t, uint32_t *win, uint32_t *wtmp)
+{
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t t0 = ld(&ctrl->t), tid = threadIdx.x;                   // t0: first step of the chunk
+    const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
+    const int et = (int)d.exposed_time, it = (int)d.infected_time;
+    const int base_idx = (int)(t0 + TE_BIAS) - et - 1 - it;               // lowest entry of the first Infected window
+    { const int k = base_idx + (int)tid; win[tid] = (k >= 0 && k < (int)TE_SLOTS) ? ld(&d.hist[k]) : 0u; }
+    __syncthreads();
+    block_scan_1024(win, wtmp);                                            // win[i] = sum of hist[base_idx .. base_idx + i]
+    if (tid < n_ahead) {
+        // Infected window of step t0 + tid: entries [tid, tid + it] of the loaded range
+        const uint32_t hi = win[tid + (uint32_t)it], lo = tid ? win[tid - 1u] : 0u;
+        d.xf[tid] = hi - lo;
+    }
+    if (tid == 0) {
+        ctrl->free_base = t0;
+        // citizens Infected in at least one step of the chunk: exposure steps [first window's low end, last window's top]
+        const uint32_t pairs = n_ahead ? win[n_ahead - 1u + (uint32_t)it] : 0u;
+        ctrl->chunk_pairs = pairs;
+        // Can this shard draw the chunk in one pass?  A citizen marks at most its home, its work building, its room and
+        // its route.  The word after the census counts the shards that cannot, so that after the all-reduce every shard
+        // takes the same form of the chunk (speculatively enqueued chunks advance on all shards or on none).
+        const bool fits = d.items_cap && d.max_route <= CHUNK_ROUTE_MAX && d.n_routes < (1u << 25) &&
+                          (unsigned long long)pairs * 4ull + 65536ull <= (unsigned long long)d.items_cap;
+        d.xf[d.xf_n] = fits ? 0u : 1u;
+    }
+}
+
+__global__ __launch_bounds__(FIN_TPB) void k_future(Dev d, uint32_t max_ahead, uint32_t limit_t)
+{
+    __shared__ uint32_t win[BF_WIN];
+    __shared__ uint32_t wtmp[FIN_TPB / 64];
+    future_body(d, max_ahead, limit_t, win, wtmp);
+}
+
+// Highest set bit index of m, -1 when m == 0.
+__device__ __forceinline__ int top_bit(unsigned long long m) { return m ? 63 - __clzll((long long)m) : -1; }
+
+// (g after f) for transition functions on the three mask states, two bits per state.
+__device__ __forceinline__ uint32_t mask_compose(uint32_t g, uint32_t f)
+{
+    return ((g >> (2u * (f & 3u))) & 3u) | (((g >> (2u * ((f >> 2) & 3u))) & 3u) << 2) | (((g >> (2u * ((f >> 4) & 3u))) & 3u) << 4);
+}
+
+__device__ __forceinline__ void decide_body(const Dev &d, uint32_t max_ahead, uint32_t limit_t, int allow_parallel)
+{
+    // One wavefront, no serial loop.  Lane l evaluates the (strict) threshold tests of steps l and 64 + l
+    // (interventions.rs:116-170).  Then, per step j of the chunk:
+    //   lockdown in force      = the lockdown test of step j - 1                     (interventions.rs:116-128)
+    //   at_work / bus_dir      = set by the last step <= j that ran its schedule arm  (citizen.rs:176-206: a locked-down
+    //                            step runs none), found with ballots and count-leading-zeros
+    //   mask status in force   = the three-state machine of interventions.rs:142-180 applied to steps 0..j-1: an
+    //                            exclusive scan of transition functions under composition
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t t0 = ld(&ctrl->t);
+    const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
+    const uint32_t lim_in = n_ahead < FREE_MAX ? n_ahead : FREE_MAX;
+    const bool ok = !ld(&ctrl->have_elig) && !ld(&ctrl->vacc_active) && !ld(&ctrl->finished) && !ld(&ctrl->error) && ld(&ctrl->free_base) == t0;
+    const uint32_t lock_init = ld(&ctrl->lockdown), mask_init = ld(&ctrl->mask), work_init = ld(&ctrl->at_work), bus_init = ld(&ctrl->bus_dir);
+    unsigned long long m_vacc[2], m_lock[2];
+    uint32_t f_mask[2];                                   // transition function of the lane's step in each round
+    bool in[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t j = 64u * r + lane;
+        in[r] = j < lim_in && t0 + j <= d.max_steps;
+        const double x = in[r] ? (double)ld(&d.xf[j]) / (double)d.n_global : 0.0;   // infected_percentage, statistics.rs:252
+        m_vacc[r] = __ballot(in[r] && d.thr_vacc < x);
+        m_lock[r] = __ballot(in[r] && d.thr_lockdown < x);
+        const uint32_t from_none = (in[r] && d.thr_mask_pt < x) ? 1u : 0u;
+        const uint32_t from_pt = !in[r] ? 1u : (x < d.thr_mask_pt ? 0u : (d.thr_mask_all < x ? 2u : 1u));
+        const uint32_t from_all = (in[r] && x < d.thr_mask_all) ? 1u : 2u;
+        f_mask[r] = from_none | (from_pt << 2) | (from_all << 4);
+    }
+    // steps before the one that starts the vaccination programme
+    uint32_t n_ok = 0;
+    if (ok) {
+        const unsigned long long valid0 = __ballot(in[0]), valid1 = __ballot(in[1]);
+        const uint32_t n_valid = (uint32_t)(__popcll(valid0) + __popcll(valid1));
+        const uint32_t first_v = m_vacc[0] ? (uint32_t)__ffsll((long long)m_vacc[0]) - 1u : (m_vacc[1] ? 64u + (uint32_t)__ffsll((long long)m_vacc[1]) - 1u : n_valid);
+        n_ok = first_v < n_valid ? first_v : n_valid;
+    }
+    // exclusive scan of the mask transition functions (identity = 0b100100)
+    uint32_t pre[2];
+    uint32_t carry = 0x24u;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        uint32_t incl = f_mask[r];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o, 64); if (lane >= (uint32_t)o) incl = mask_compose(incl, y); }
+        uint32_t excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 0x24u;
+        pre[r] = mask_compose(excl, carry);               // everything before this step, earlier round first
+        carry = mask_compose(__shfl(incl, 63, 64), carry);
+    }
+    const Decision none = { 0u, 0u, 0u, 0u };
+    Decision mine[2] = { none, none };
+    unsigned long long run_mask[2];                       // steps that run their schedule arm (not locked down)
+    uint32_t lockd[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t j = 64u * r + lane;
+        const bool prev_lock = j == 0 ? lock_init != 0u : (j == 64u ? ((m_lock[0] >> 63) & 1ull) != 0ull : ((m_lock[r] >> (lane - 1u)) & 1ull) != 0ull);
+        lockd[r] = prev_lock ? 1u : 0u;
+        run_mask[r] = __ballot(!prev_lock);
+    }
+    // at_work and bus_dir: last deciding step at or before j, over both rounds
+    unsigned long long s1[2], s0[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t h = (t0 + 64u * r + lane) % 24u;
+        s1[r] = __ballot(!lockd[r] && h == d.start_hour);
+        s0[r] = __ballot(!lockd[r] && h == d.end_hour);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const unsigned long long le = lane == 63u ? ~0ull : ((1ull << (lane + 1u)) - 1ull);
+        // position: the latest "starts work" / "goes home" arm among the steps that ran
+        int last1 = top_bit(s1[r] & le), last0 = top_bit(s0[r] & le);
+        if (r == 1) { last1 = last1 >= 0 ? last1 + 64 : top_bit(s1[0]); last0 = last0 >= 0 ? last0 + 64 : top_bit(s0[0]); }
+        const uint32_t at_work = last1 > last0 ? 1u : (last0 > last1 ? 0u : work_init);
+        // bus: the latest step that ran any arm decides (every arm assigns on_public_transport)
+        int last_run = top_bit(run_mask[r] & le);
+        if (r == 1) last_run = last_run >= 0 ? last_run + 64 : top_bit(run_mask[0]);
+        uint32_t bus_dir = bus_init;
+        if (last_run >= 0) {
+            const uint32_t hh = (t0 + (uint32_t)last_run) % 24u;
+            bus_dir = hh == d.start_hour - 1u ? 1u : (hh == d.end_hour - 1u ? 2u : 0u);
+        }
+        const uint32_t msk = (pre[r] >> (2u * mask_init)) & 3u;
+        mine[r] = Decision{ lockd[r], msk, at_work, bus_dir };
+    }
+    // what is in force after the chunk = what would be in force during step n_ok, except that position and bus
+    // are those of step n_ok - 1 (k_batch_finish reads them from there)
+    if (lane < n_ok) d.dec[lane] = mine[0];
+    if (64u + lane < n_ok) d.dec[64u + lane] = mine[1];
+    {
+        // entry n_ok: lockdown / mask after the last step of the chunk; computed by the lane that owns step n_ok when
+        // it exists in the arrays, else from the scan totals
+        const uint32_t jn = n_ok;
+        uint32_t lock_after, mask_after;
+        if (jn == 0) { lock_after = lock_init; mask_after = mask_init; }
+        else {
+            const uint32_t jl = jn - 1u;                                  // last step of the chunk
+            lock_after = (uint32_t)((m_lock[jl >> 6] >> (jl & 63u)) & 1ull);
+            // mask after step jl = f_jl applied to the mask in force during jl
+            const uint32_t f_last = __shfl(jl < 64u ? f_mask[0] : f_mask[1], (int)(jl & 63u), 64);
+            const uint32_t pre_last = __shfl(jl < 64u ? pre[0] : pre[1], (int)(jl & 63u), 64);
+            mask_after = (mask_compose(f_last, pre_last) >> (2u * mask_init)) & 3u;
+        }
+        const uint32_t aw_last = jn ? __shfl(jn - 1u < 64u ? mine[0].at_work : mine[1].at_work, (int)((jn - 1u) & 63u), 64) : work_init;
+        const uint32_t bd_last = jn ? __shfl(jn - 1u < 64u ? mine[0].bus_dir : mine[1].bus_dir, (int)((jn - 1u) & 63u), 64) : bus_init;
+        if (lane == 0) d.dec[jn] = Decision{ lock_after, mask_after, aw_last, bd_last };
+    }
+    const unsigned long long bus_m0 = __ballot(lane < n_ok && mine[0].bus_dir != 0u), bus_m1 = __ballot(64u + lane < n_ok && mine[1].bus_dir != 0u);
+    for (uint32_t i = lane; i < HOT_RESET; i += 64u) d.hot[i * HOT_STRIDE] = 0u;
+    if (lane == 0) {
+        ctrl->chunk_ok = n_ok; ctrl->chunk_t0 = t0;
+        // the log slice of everybody Infected in some step of the chunk (k_chunk_marks starts from it)
+        const int lo_te = (int)(t0 + TE_BIAS) - (int)d.exposed_time - 1 - (int)d.infected_time;
+        const int hi_te = (int)(t0 + n_ok + TE_BIAS) - (int)d.exposed_time - 2;
+        ctrl->chunk_i0 = (hi_te < 0 || n_ok == 0u) ? 0u : ld(&d.log_off[lo_te < 0 ? 0 : lo_te]);
+        ctrl->chunk_i1 = (hi_te < 0 || n_ok == 0u) ? 0u : ld(&d.log_off[hi_te + 1]);
+        // riders are on a bus in at most CHUNK_BUS_STEPS steps of a one-pass chunk (two a day unless a lockdown froze them
+        // there, Q8): that bounds the (route, bus step) pairs a wavefront of k_chunk_marks can register.  The same on all shards.
+        const uint32_t bus_steps = (uint32_t)(__popcll(bus_m0) + __popcll(bus_m1));
+        ctrl->chunk_parallel = (allow_parallel && ld(&d.xf[d.xf_n]) == 0u && bus_steps <= CHUNK_BUS_STEPS) ? 1u : 0u;
+        ctrl->n_items = 0u; ctrl->n_newexp = 0u; ctrl->n_units = 0u; ctrl->unit_next = 0u; ctrl->n_route_pairs = 0u; ctrl->n_route_pairs_big = 0u;
+    }
+    d.cursor[lane] = 0u;
+    if (lane < FREE_MAX - 64u) d.cursor[64u + lane] = 0u;
+}
+
+__global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32_t limit_t, int allow_parallel)
+{
+    decide_body(d, max_ahead, limit_t, allow_parallel);
+}
+
+// Marks of the first step of a chunk (the later ones are made by the k_pipe of the step before).
+// ------------------------------------------------------------------------- time-parallel chunk
+// Inside a chunk nothing a draw depends on changes: who is Infected and where (known ahead), the mask
+// status, the Philox counters.  A citizen's exposure step is therefore simply the EARLIEST step at which any of
+// its draws succeeds (later draws would have been skipped by `is_susceptible()`, simulator.rs:337), and within a
+// step a building exposure precedes a bus exposure (simulator.rs:268-401).  With the exposure step in the top
+// bits of the citizen word and the bus bit right below, that is one atomicMin per successful draw -- so all
+// steps of the chunk are drawn in ONE pass.
+//   k_chunk_marks  an item per building / room / route that somebody Infected stands in during the chunk, and per item the
+//                  stretches of steps in which each of them stands there (generate_exposures)
+//   k_chunk_draw   the (member, marked step) pairs of every item, densely over the lanes (apply_exposures); long member
+//                  lists are cut into units
+//   k_chunk_units  the units, dealt evenly; routes of more than 64 riders
+//   k_chunk_books  exposure counts, records, log entries, clean-up, the next chunk's decisions
+//                  (k_chunk_count / k_chunk_scatter: its two wide parts as kernels of their own while many are Infected)
+__device__ __forceinline__ uint32_t hash64(unsigned long long k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (uint32_t)k;
+}
+
+// Items live in an open-addressing hash map keyed by (building | n_bld + room | n_bld + n_room + route).  Whoever
+// inserts the key claims the item: it takes the next id of its wavefront's own id range (a counter bumped once per claim
+// would serialise the pass) and writes the item's record.  Everything the others add to the item -- their interval
+// records, the per-step counters of those that found no record free, a route's registered bus steps -- is indexed by the
+// hash SLOT, which the probe itself returns: nobody ever waits for anybody.
+#define ITEM_UNUSED 0xFFFFFFFFu
+__device__ __forceinline__ bool item_probe(const Dev &d, Ctrl *ctrl, unsigned long long key, uint32_t &slot, bool &pending)
+{
+    uint32_t h = hash64(key) & (d.hcap - 1u);
+    pending = false;
+    for (uint32_t probe = 0; probe < d.hcap; ++probe) {
+        const unsigned long long old = atomicCAS(&d.hkey[h], HKEY_EMPTY, key);
+        if (old == HKEY_EMPTY) { slot = h; return true; }
+        if (old == key) { slot = h; pending = true; return false; }
+        h = (h + 1u) & (d.hcap - 1u);
+    }
+    ctrl->error = (uint32_t)(-ESIM_ERANGE);
+    slot = 0u;
+    return false;
+}
+
+// An interval record: a citizen that is Infected in steps [a, b] of the chunk, the flags that decide where it stands
+// in each of them, and whether the record sits in its work building / room or in its home.
+#define IV_VALID   0x80000000u
+#define IV_PT      (1u << 14)
+#define IV_HW      (1u << 15)
+#define IV_AS_WORK (1u << 16)
+__device__ __forceinline__ uint32_t iv_present(uint32_t iv, uint32_t j, const Decision &q)
+{
+    if (!(iv & IV_VALID) || j < (iv & 127u) || j > ((iv >> 7) & 127u)) return 0u;
+    if (q.bus_dir && (iv & IV_PT)) return 0u;                                 // on a bus (simulator.rs:181-186)
+    const bool at_work = q.at_work && (iv & IV_HW);
+    return ((iv & IV_AS_WORK) != 0u) == at_work ? 1u : 0u;
+}
+
+// Where an Infected citizen stands in step s of the chunk (simulator.rs:181-198): bit 0 in the home building,
+// bit 1 in the work building, bit 2 on the bus.  0 when not Infected in that step.
+__device__ __forceinline__ uint32_t where_in_step(const Dev &d, uint32_t w, uint32_t s, const Decision &q)
+{
+    if (status_of(CW_TE(w), s, d.exposed_time, d.infected_time) != ESIM_INFECTED) return 0u;
+    if (q.bus_dir && (w & FL_USES_PT)) return 4u;
+    return (q.at_work && (w & FL_HAS_WORK)) ? 2u : 1u;
+}
+
+// generate_exposures (simulator.rs:181-198) for every step of the chunk: one wavefront per citizen that is
+// Infected somewhere in the chunk; lanes are the steps (two rounds of 64).
+__global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
+{
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t t0 = ctrl->chunk_t0, n = ctrl->chunk_ok;
+    if (!ctrl->chunk_parallel || n == 0u) return;
+    {
+        // the marks of step t0 - 1 (made by a sequential or pipelined step) would have been cleared by the exposure
+        // pass of step t0; this chunk has none, so clear them here
+        const uint32_t q = (t0 + MARK_SLOTS - 1u) & (MARK_SLOTS - 1u);
+        const uint32_t tid = blockIdx.x * TPB + threadIdx.x, nth = gridDim.x * TPB;
+        const uint32_t ob = ctrl->n_touched_bld[q], orr = ctrl->n_touched_room[q], ort = ctrl->n_touched_route[q], orb = ctrl->n_touched_route_big[q];
+        for (uint32_t i = tid; i < ob; i += nth) d.cnt_bld[q][d.touched_bld[q][i]] = 0u;
+        for (uint32_t i = tid; i < orr; i += nth) d.cnt_room[q][d.touched_room[q][i]] = 0u;
+        for (uint32_t i = tid; i < ort; i += nth) d.route_flag[q][d.touched_route[q][i]] = 0u;
+        for (uint32_t i = tid; i < orb; i += nth) d.route_flag[q][d.touched_route_big[q][i]] = 0u;
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    const uint32_t i0 = ctrl->chunk_i0, i1 = ctrl->chunk_i1;                 // log slice of the chunk's Infected (k_decide)
+    // every wavefront owns a fixed range of item ids (a citizen claims at most four items), so no counter is shared
+    const uint32_t per_wave = 4u * ((i1 - i0 + n_waves - 1u) / n_waves);
+    if (wave == 0 && lane == 0) { ctrl->items_per_wave = per_wave; ctrl->n_items = per_wave * n_waves; }
+    if ((unsigned long long)per_wave * n_waves > d.items_cap) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); return; }
+    for (uint32_t i = lane; i < per_wave; i += 64u) d.hitems[wave * per_wave + i] = ITEM_UNUSED;
+    uint32_t next_id = wave * per_wave;
+    const Decision q0 = lane < n ? d.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
+    const Decision q1 = 64u + lane < n ? d.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
+    // The steps of the chunk in which riders are on a bus, in order (at most CHUNK_BUS_STEPS, k_decide): a route item keeps
+    // one bit per such step -- "an Infected rider of this route has registered the (route, step) pair".
+    const unsigned long long busm0 = __ballot(lane < n && q0.bus_dir != 0u), busm1 = __ballot(64u + lane < n && q1.bus_dir != 0u);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t bidx0 = (uint32_t)__popcll(busm0 & lt), bidx1 = (uint32_t)(__popcll(busm0) + __popcll(busm1 & lt));   // index of my step among them
+    // lanes 0..3 own one key each: home building, work building, room, route.  The entry after this one is fetched
+    // (log entry, word, the lane's key source) before the work on this one: the hash claim's round trips overlap it.
+    const uint32_t *key_src = lane == 0 ? d.home : lane == 1 ? d.work : lane == 2 ? d.room : d.route_of;
+    const uint32_t pm0 = PROF_NOW();
+    uint32_t p_entries = 0u;
+    uint32_t my_pairs = 0u;                                                   // (route, bus step) pairs this wavefront registered
+    uint32_t c_n = 0u, w_n = 0u, k_n = 0u;
+    if (i0 + wave < i1) { c_n = d.log[i0 + wave]; w_n = d.cit[c_n]; if (lane < 4u) k_n = key_src[c_n]; }
+    uint32_t ps[5] = { 0u, 0u, 0u, 0u, 0u };                                   // diagnostics: time per stage
+    const uint32_t pm_loop = PROF_NOW();
+    for (uint32_t e = i0 + wave; e < i1; e += n_waves) {
+        const uint32_t w = w_n, ksrc = k_n;
+        const uint32_t pa = PROF_NOW();
+        if (e + n_waves < i1) { c_n = d.log[e + n_waves]; w_n = d.cit[c_n]; if (lane < 4u) k_n = key_src[c_n]; }
+        const uint32_t p0 = lane < n ? where_in_step(d, w, t0 + lane, q0) : 0u;
+        const uint32_t p1 = 64u + lane < n ? where_in_step(d, w, t0 + 64u + lane, q1) : 0u;
+        const bool any_home = __any((p0 | p1) & 1u), any_work = __any((p0 | p1) & 2u), any_bus = __any((p0 | p1) & 4u);
+        const bool school = w & FL_WORK_SCHOOL;
+        if (!any_home && !any_work && !any_bus) continue;
+        ++p_entries;
+        const uint32_t pb = PROF_NOW();
+        // the citizen is Infected in steps [a, b] of the chunk (one stretch: disease.rs:60-65); where it stands in each of
+        // them follows from the record's flags and the step's schedule (iv_present)
+        const int a_abs = (int)CW_TE(w) - (int)TE_BIAS + (int)d.exposed_time + 1;
+        const uint32_t iv_a = a_abs > (int)t0 ? (uint32_t)(a_abs - (int)t0) : 0u;
+        const uint32_t iv_b = min((uint32_t)(a_abs + (int)d.infected_time - (int)t0), n - 1u);
+        const uint32_t iv = IV_VALID | iv_a | (iv_b << 7) | ((w & FL_USES_PT) ? IV_PT : 0u) | ((w & FL_HAS_WORK) ? IV_HW : 0u) |
+                            ((lane == 1u || lane == 2u) ? IV_AS_WORK : 0u);
+        unsigned long long key = HKEY_EMPTY;
+        if (lane == 0 && any_home) key = ksrc;
+        if (lane == 1 && any_work) key = ksrc;
+        if (lane == 2 && any_work && school) key = (unsigned long long)d.n_bld + ksrc;
+        if (lane == 3 && any_bus) key = (unsigned long long)d.n_bld + d.n_room + ksrc;
+        uint32_t slot = 0u;
+        bool pending = false, claimed = false;
+        if (key != HKEY_EMPTY) claimed = item_probe(d, ctrl, key, slot, pending);
+        const unsigned long long cm = __ballot(claimed);
+        const uint32_t pc = PROF_NOW();
+        const uint32_t s_home = __shfl(slot, 0, 64), s_work = __shfl(slot, 1, 64), s_room = __shfl(slot, 2, 64);
+        if (claimed) {
+            const uint32_t v = next_id + (uint32_t)__popcll(cm & lt);
+            d.hitems[v] = slot;
+            // what the draw pass needs of the item; the claimer's own stretch travels in it, and a room's record names the
+            // slot of its school (the citizen's work building, lane 1)
+            const uint32_t id = (uint32_t)key;
+            // (a school's counts are looked up by slot from its rooms, so even its claimer's stretch goes into a slot record)
+            ItemRec rec = { id, 0u, 0u, 0u, 0u, 0u, lane == 2u ? s_work : 0xFFFFFFFFu, (lane < 3u && !(lane == 1u && school)) ? iv : 0u };
+            // (pointer selects, not branches: the loads of a building lane and of a room lane go out together)
+            const bool is_bld = id < d.n_bld, is_room = !is_bld && id < d.n_bld + d.n_room;
+            if (is_bld || is_room) {
+                const uint32_t r = is_bld ? id : id - d.n_bld;
+                const uint32_t *pa = (is_bld ? d.res_off : d.room_off) + r;
+                const uint32_t a_lo = pa[0], a_hi = pa[1];
+                const uint32_t b_lo = is_bld ? d.wrk_off[r] : 0u, b_hi = is_bld ? d.wrk_off[r + 1] : 0u;
+                const uint32_t aux = is_bld ? (uint32_t)d.bld_type[r] : d.room_bld[r];
+                rec.a_lo = a_lo; rec.a_hi = a_hi; rec.b_lo = b_lo; rec.b_hi = b_hi; rec.aux = aux;
+            }
+            d.item_rec[v] = rec;
+        }
+        next_id += (uint32_t)__popcll(cm);
+        const uint32_t pd = PROF_NOW();
+        // Somebody else's building / room: my stretch goes into one of the slot's ITEM_RECS records; when they are taken,
+        // into its per-step counters (`vec`), one atomic per step.  The route: which of my bus steps nobody has registered yet.
+        uint32_t mine = 0u;                                                   // bit i: I ride, Infected, in the i-th bus step of the chunk
+        if (any_bus) {
+            const unsigned long long r0 = __ballot((p0 & 4u) != 0u), r1 = __ballot((p1 & 4u) != 0u);
+            for (unsigned long long m = busm0 & r0; m; m &= m - 1ull) mine |= 1u << __popcll(busm0 & ((m & (0ull - m)) - 1ull));
+            for (unsigned long long m = busm1 & r1; m; m &= m - 1ull) mine |= 1u << (__popcll(busm0) + __popcll(busm1 & ((m & (0ull - m)) - 1ull)));
+        }
+        const bool add_rec = lane < 3u && (pending || (claimed && lane == 1u && school));
+        const bool reg_bus = lane == 3u && any_bus;
+        uint32_t old = 0u;
+        if (add_rec || reg_bus) {
+            // lanes 0..2 take a record position (+1), lane 3 sets its bus-step bits: two atomic instructions, one wait
+            if (reg_bus) old = atomicOr(&d.slot_state[slot], mine);
+            else old = atomicAdd(&d.slot_state[slot], 1u);
+        }
+        bool spill = false;
+        if (add_rec) { if (old < ITEM_RECS) d.slot_iv[(size_t)slot * 8u + old] = iv; else spill = true; }
+        const uint32_t new_bits = __shfl(reg_bus ? (mine & ~old) : 0u, 3, 64);
+        const bool sp_home = __shfl((int)spill, 0, 64), sp_work = __shfl((int)spill, 1, 64), sp_room = __shfl((int)spill, 2, 64);
+        const uint32_t pe = PROF_NOW();
+        if (sp_home) {
+            if (p0 & 1u) atomicAdd(&d.vec[(size_t)s_home * FREE_MAX + lane], 1u);
+            if (p1 & 1u) atomicAdd(&d.vec[(size_t)s_home * FREE_MAX + 64u + lane], 1u);
+        }
+        if (sp_work) {
+            if (p0 & 2u) atomicAdd(&d.vec[(size_t)s_work * FREE_MAX + lane], 1u);
+            if (p1 & 2u) atomicAdd(&d.vec[(size_t)s_work * FREE_MAX + 64u + lane], 1u);
+        }
+        if (sp_room) {
+            if (p0 & 2u) atomicAdd(&d.vec[(size_t)s_room * FREE_MAX + lane], 1u);
+            if (p1 & 2u) atomicAdd(&d.vec[(size_t)s_room * FREE_MAX + 64u + lane], 1u);
+        }
+        if (new_bits) {
+            // register the (route, step) pairs that are new: k_chunk_draw ranks the riders of each once
+            const bool f0 = (p0 & 4u) && ((new_bits >> bidx0) & 1u), f1 = (p1 & 4u) && ((new_bits >> bidx1) & 1u);
+            const uint32_t rt = __shfl(ksrc, 3, 64);                          // the route itself, not its item: saves the pass a hop
+            const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
+            const uint32_t add = (uint32_t)(__popcll(m0) + __popcll(m1));     // <= CHUNK_BUS_STEPS (k_decide)
+            if (!(w & FL_BIG_ROUTE)) {
+                // this wavefront's own stretch of the list: no shared counter
+                uint32_t *list = d.route_pairs + (size_t)wave * 2u * per_wave;
+                if (my_pairs + add <= 2u * per_wave) {
+                    if (f0) list[my_pairs + (uint32_t)__popcll(m0 & lt)] = (rt << 7) | lane;
+                    if (f1) list[my_pairs + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1 & lt)] = (rt << 7) | (64u + lane);
+                    my_pairs += add;
+                } else if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE);
+            } else {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&d.hot[HOT_BIGPAIRS * HOT_STRIDE], add);
+                base = __shfl(base, 0, 64);
+                if (base + add <= 2u * d.items_cap) {
+                    if (f0) d.route_pairs_big[base + (uint32_t)__popcll(m0 & lt)] = (rt << 7) | lane;
+                    if (f1) d.route_pairs_big[base + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1 & lt)] = (rt << 7) | (64u + lane);
+                } else if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE);
+            }
+        }
+        { const uint32_t pf = PROF_NOW(); ps[0] += pb - pa; ps[1] += pc - pb; ps[2] += pd - pc; ps[3] += pe - pd; ps[4] += pf - pe; }
+    }
+    if (lane == 0) { d.pair_cnt[wave] = my_pairs; d.used_cnt[wave] = next_id - wave * per_wave; }
+    const uint32_t pm1 = PROF_NOW();
+    PROF_PUT(d, 8, pm0); PROF_PUT(d, 9, pm1); PROF_PUT(d, 10, p_entries);
+    PROF_PUT(d, 11, ps[0]); PROF_PUT(d, 12, ps[1]); PROF_PUT(d, 13, ps[2]); PROF_PUT(d, 14, ps[3]); PROF_PUT(d, 15, ps[4]);
+    PROF_PUT(d, 6, pm_loop - pm0);
+}
+
+// A successful draw of citizen m in step s (bus: on public transport).
+__device__ __forceinline__ void expose_min(const Dev &d, Ctrl *ctrl, uint32_t m, uint32_t w, uint32_t s, uint32_t bus)
+{
+    const uint32_t cand = CW_MAKE(s + TE_BIAS, bus | (w & CW_FLAGS));
+    const uint32_t prev = atomicMin(&d.cit[m], cand);
+    if (cand < prev && CW_TE(prev) == TE_SUSCEPTIBLE) {                       // first exposure in this chunk
+        const uint32_t r = m & (SUBQ - 1u);
+        d.newexp[(size_t)r * d.newexp_cap + atomicAdd(&d.hot[(HOT_NEWEXP + r) * HOT_STRIDE], 1u)] = m;
+    }
+}
+
+struct ChunkShared {
+    Decision dec[FREE_MAX];
+    uint64_t thr[512];
+};
+struct RouteShared {
+    uint32_t s_key[CHUNK_ROUTE_MAX];
+    uint16_t s_bus[CHUNK_ROUTE_MAX];
+    uint8_t s_inf[CHUNK_ROUTE_MAX];
+    uint32_t s_cnt[CHUNK_ROUTE_MAX + 1];
+};
+struct WaveScratch { uint32_t cnt[FREE_MAX]; uint32_t sch[FREE_MAX]; uint32_t mem_id[64]; uint32_t mem_w[64]; uint8_t steps[FREE_MAX]; };
+
+// One member list of one item over the marked steps of the chunk: the (member, marked step) pairs [p_lo, p_hi) are
+// spread densely over the 64 lanes (the draws are Philox-bound -- 20 quarter-rate multiplies each -- so idle lanes
+// are what costs).  ws.steps: the item's marked steps in order, S of them; ws.cnt / ws.sch: the item's / the school's
+// Infected per step.  kind 0 residents, 1 workers, 2 room participants.
+// pre_m / pre_w: members lo + pre_base + lane of the list and their words when the caller has already fetched them (have_pre).
+__device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, WaveScratch &ws, const uint32_t *idx,
+                                             uint32_t lo, uint32_t p_lo, uint32_t p_hi, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0,
+                                             bool have_pre = false, uint32_t pre_m = 0u, uint32_t pre_w = 0u, uint32_t pre_base = 0u)
+{
+    const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
+    // members touched by the pairs [p_lo, p_hi): staged in LDS 64 at a time -- every member recurs once per marked step
+    const uint32_t m_first = p_lo / S, m_last = (p_hi - 1u) / S;
+    for (uint32_t mb = m_first; mb <= m_last; mb += 64u) {
+        __builtin_amdgcn_wave_barrier();
+        if (mb + lane <= m_last) {
+            if (have_pre && mb == pre_base) { ws.mem_id[lane] = pre_m; ws.mem_w[lane] = pre_w; }
+            else {
+                const uint32_t m = idx ? idx[lo + mb + lane] : lo + mb + lane;
+                ws.mem_id[lane] = m;
+                ws.mem_w[lane] = d.cit[m];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t q_lo = max(p_lo, mb * S), q_hi = min(p_hi, (mb + 64u) * S);
+        for (uint32_t p = q_lo + lane; p < q_hi; p += 64u) {
+            const uint32_t um = p / S, j = ws.steps[p - um * S];
+            const uint32_t m = ws.mem_id[um - mb], w = ws.mem_w[um - mb];
+            const uint32_t te = CW_TE(w), s = t0 + j;
+            if (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) continue;
+            // Susceptible when this list is walked in step s: never exposed, or so far only exposed by something that
+            // comes later (a later step, or a bus of this step) -- that exposure may be undercut
+            if (w <= CW_MAKE(s + TE_BIAS, w & CW_FLAGS)) continue;
+            const uint32_t at_work = sm.dec[j].at_work, mask = sm.dec[j].mask;
+            const bool same = w & FL_SAME_AREA;
+            if (kind == 0u) { if (at_work && (w & FL_HAS_WORK) && !same) continue; }       // simulator.rs:324
+            else if (!at_work && !same) continue;
+            const uint32_t cnt = ws.cnt[j];
+            const uint32_t nn = kind == 2u ? ws.sch[j] : cnt;                               // exposure_count: infected in the building
+            const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
+            const uint64_t thr = sm.thr[row * 256u + (nn & 255u)];
+            const uint32_t gid = d.id_base + m;
+            bool hit = false;
+            if (kind == 2u) { for (uint32_t k = 0; k < cnt && !hit; ++k) hit = esim_u53(seed, gid, s, ESIM_SLOT_ROOM0 + k) < thr; }
+            else hit = esim_u53(seed, gid, s, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK) < thr;
+            if (hit) expose_min(d, ctrl, m, w, s, 0u);
+        }
+    }
+}
+
+// The marked steps of item v, in order, and its per-step counts, into this wavefront's scratch.  Returns S.
+__device__ __forceinline__ uint32_t item_steps_regs(uint32_t c0, uint32_t c1, uint32_t lane, WaveScratch &ws)
+{
+    ws.cnt[lane] = c0;
+    if (lane < FREE_MAX - 64u) ws.cnt[64u + lane] = c1;
+    const unsigned long long b0 = __ballot(c0 != 0u), b1 = __ballot(c1 != 0u);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (c0) ws.steps[__popcll(b0 & lt)] = (uint8_t)lane;
+    if (c1) ws.steps[__popcll(b0) + __popcll(b1 & lt)] = (uint8_t)(64u + lane);
+    return (uint32_t)(__popcll(b0) + __popcll(b1));
+}
+
+__device__ __forceinline__ uint32_t fetch_slot(const Dev &d, uint32_t slot, uint32_t lane);
+__device__ __forceinline__ void item_counts(const Dev &d, uint32_t x, uint32_t slot, uint32_t lane, uint32_t n, const Decision &q0,
+                                            const Decision &q1, uint32_t &c0, uint32_t &c1);
+__device__ __forceinline__ void school_counts(const Dev &d, uint32_t s_sch, uint32_t lane, uint32_t n, const Decision &q0, const Decision &q1, WaveScratch &ws)
+{
+    // s_sch: the hash slot of the room's school (k_chunk_marks left it in the room's record): infected in the whole school, per
+    // step.  All of a school's stretches are slot records (k_chunk_marks), so the slot alone gives the count.
+    uint32_t c0 = 0u, c1 = 0u;
+    if (s_sch != 0xFFFFFFFFu) { const uint32_t x = fetch_slot(d, s_sch, lane); item_counts(d, x, s_sch, lane, n, q0, q1, c0, c1); }
+    ws.sch[lane] = c0;
+    if (lane < FREE_MAX - 64u) ws.sch[64u + lane] = c1;
+}
+
+// Lists with more pairs than this are cut into units that any wavefront can take (k_chunk_units), so that one
+// 200-member workplace does not keep a single wavefront busy while the chip idles.
+// A deferred unit carries everything its consumer needs, so that it is three dependent loads away from drawing: the
+// item's hash slot and its claimer's stretch (the Infected per step), the school's slot for a room, the member list, and
+// where in it the unit's first pair falls.
+struct UnitSrc { uint32_t slot, link, own; };
+__device__ __forceinline__ void list_or_units(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, WaveScratch &ws, const uint32_t *idx,
+                                              uint32_t lo, uint32_t hi, const UnitSrc &src, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0,
+                                              bool have_pre = false, uint32_t pre_m = 0u, uint32_t pre_w = 0u)
+{
+    const uint32_t pairs = (hi - lo) * S;
+    if (pairs == 0) return;
+    if (pairs <= UNIT_PAIRS) { member_pairs(d, ctrl, sm, ws, idx, lo, 0u, pairs, lane, kind, S, t0, have_pre, pre_m, pre_w); return; }
+    const uint32_t n_units = (pairs + UNIT_PAIRS - 1u) / UNIT_PAIRS;
+    const uint32_t r = ((blockIdx.x * TPB + threadIdx.x) >> 6) & (SUBQ - 1u);  // this wavefront's queue
+    uint32_t start = 0;
+    if (lane == 0) start = atomicAdd(&d.hot[(HOT_UNITS + r) * HOT_STRIDE], n_units);
+    start = __shfl(start, 0, 64);
+    UnitRec *q = d.units + (size_t)r * d.unit_qcap;
+    if (start + n_units > d.unit_qcap) {
+        // queue full: what was reserved of it becomes no-ops and the list is drawn here
+        for (uint32_t i = lane; i < n_units && start + i < d.unit_qcap; i += 64u) q[start + i].code = UNIT_NOOP;
+        member_pairs(d, ctrl, sm, ws, idx, lo, 0u, pairs, lane, kind, S, t0, have_pre, pre_m, pre_w);
+        return;
+    }
+    for (uint32_t i = lane; i < n_units; i += 64u) {
+        const uint32_t p_lo = i * UNIT_PAIRS;
+        q[start + i] = UnitRec{ src.slot, kind == 2u ? src.link : 0xFFFFFFFFu, lo, hi - lo, (kind << 30) | p_lo, src.own, p_lo / S, 0u };
+    }
+}
+
+// What a wavefront needs of item v before it can start on it; depends on v alone, so the fetch of the next item is
+// issued before the work on the current one (the pass is bound by chains of dependent loads, not by bandwidth).
+// The fetch of an item is one register in two hops: lanes 0..7 its record and lane 17 its hash slot (ITEM_UNUSED: id not
+// handed out) by item id; then lanes 8..14 the slot's interval records and lane 16 their number by slot.
+struct ItemFetch { uint32_t slot, id, a_lo, a_hi, b_lo, b_hi, aux, link, c0, c1; };
+#define FX(x, i) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (i)))
+__device__ __forceinline__ uint32_t fetch_item(const Dev &d, uint32_t v, uint32_t lane)
+{
+    uint32_t x = 0u;
+    if (lane < 8u) x = reinterpret_cast<const uint32_t *>(d.item_rec)[(size_t)v * 8u + lane];
+    else if (lane == 17u) x = d.hitems[v];
+    return x;
+}
+__device__ __forceinline__ uint32_t fetch_slot(const Dev &d, uint32_t slot, uint32_t lane)
+{
+    uint32_t x = 0u;
+    if (slot != ITEM_UNUSED) {
+        if (lane >= 8u && lane < 8u + ITEM_RECS) x = d.slot_iv[(size_t)slot * 8u + (lane - 8u)];
+        else if (lane == 16u) x = d.slot_state[slot];
+    }
+    return x;
+}
+__device__ __forceinline__ uint32_t merge_fetch(uint32_t by_id, uint32_t by_slot, uint32_t lane)
+{
+    return (lane < 8u || lane == 17u) ? by_id : by_slot;
+}
+
+// Infected standing in the item in step `lane` (c0) and `64 + lane` (c1) of the chunk: the records of its slot, plus the
+// per-step counters of those that found no record free.  (The claimer's own stretch is added by decode_item.)
+__device__ __forceinline__ void item_counts(const Dev &d, uint32_t x, uint32_t slot, uint32_t lane, uint32_t n, const Decision &q0,
+                                            const Decision &q1, uint32_t &c0, uint32_t &c1)
+{
+    const uint32_t state = FX(x, 16);
+    c0 = 0u; c1 = 0u;
+    if (state > ITEM_RECS) {
+        if (lane < n) c0 = d.vec[(size_t)slot * FREE_MAX + lane];
+        if (64u + lane < n) c1 = d.vec[(size_t)slot * FREE_MAX + 64u + lane];
+    }
+    const uint32_t n_rec = state < ITEM_RECS ? state : ITEM_RECS;
+    for (uint32_t k = 0; k < n_rec; ++k) {
+        const uint32_t iv = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)(8u + k));
+        if (lane < n) c0 += iv_present(iv, lane, q0);
+        if (64u + lane < n) c1 += iv_present(iv, 64u + lane, q1);
+    }
+}
+
+__device__ __forceinline__ ItemFetch decode_item(const Dev &d, uint32_t x, uint32_t lane, uint32_t n, const Decision &q0, const Decision &q1)
+{
+    ItemFetch f;
+    f.slot = FX(x, 17); f.id = FX(x, 0); f.a_lo = FX(x, 1); f.a_hi = FX(x, 2); f.b_lo = FX(x, 3); f.b_hi = FX(x, 4); f.aux = FX(x, 5); f.link = FX(x, 6);
+    f.c0 = 0u; f.c1 = 0u;
+    if (f.slot != ITEM_UNUSED) {
+        item_counts(d, x, f.slot, lane, n, q0, q1, f.c0, f.c1);
+        const uint32_t own = FX(x, 7);
+        if (lane < n) f.c0 += iv_present(own, lane, q0);
+        if (64u + lane < n) f.c1 += iv_present(own, 64u + lane, q1);
+    }
+    return f;
+}
+
+#define PAIR_SPREAD 1237u
+// apply_exposures (simulator.rs:262-405) for every item and every step of the chunk.
+__global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
+{
+    __shared__ ChunkShared sm;
+    __shared__ WaveScratch wsc[TPB / 64];
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t t0 = ctrl->chunk_t0, n = ctrl->chunk_ok;
+    if (!ctrl->chunk_parallel || n == 0u) return;
+    const uint32_t n_items = min(ld(&ctrl->n_items), d.items_cap);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    const uint32_t pt0 = PROF_NOW();
+    uint32_t p_items = 0u, p_item_max = 0u;
+    // the items claimed by the wavefront of the same index in k_chunk_marks (same grid): ids [wave * per_wave, ...), handed
+    // out in order, so the first unused id ends the list.  (Striding over all ids instead would pile the items onto
+    // the few wavefronts whose index matches the low ids of every range.)
+    const uint32_t per_wave = ld(&ctrl->items_per_wave);
+    const uint32_t v_lo = wave * per_wave, v_hi = min(v_lo + per_wave, n_items);
+    // three items in flight: the record of the one after next (by id), the slot records of the next (by its slot), this one
+    uint32_t id_cur = 0u, id_nxt = 0u, sl_cur = 0u;
+    if (v_lo < v_hi) id_cur = fetch_item(d, v_lo, lane);
+    if (v_lo + 1u < v_hi) id_nxt = fetch_item(d, v_lo + 1u, lane);
+    // ... and the first look at the (route, bus step) pairs dealt to this wavefront (phase 2 below), so that they are here
+    // when the items are done
+    const uint32_t K = 2u * per_wave;                                          // pairs a stretch of the list can hold
+    uint32_t code_l = 0u, off_l = 0u, sz_l = 0u;
+    bool have = false;
+    if (lane < K) {
+        const uint32_t src = (wave + n_waves - (uint32_t)(((unsigned long long)lane * PAIR_SPREAD) % n_waves)) % n_waves;
+        have = lane < d.pair_cnt[src];
+        code_l = d.route_pairs[(size_t)src * K + lane];                       // in bounds whether or not the pair exists
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
+    for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
+    __syncthreads();
+    const uint32_t route_base = d.n_bld + d.n_room;
+    WaveScratch &ws = wsc[threadIdx.x >> 6];
+    const Decision q0 = lane < n ? sm.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
+    const Decision q1 = 64u + lane < n ? sm.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
+    if (v_lo < v_hi) sl_cur = fetch_slot(d, FX(id_cur, 17), lane);
+    if (have) { const uint32_t r = code_l >> 7; off_l = d.route_off[r]; sz_l = d.route_off[r + 1] - off_l; }
+    const uint32_t pt1 = PROF_NOW();
+    // (1) buildings and school rooms: one wavefront per item
+    for (uint32_t v = v_lo; v < v_hi; ++v) {
+        const uint32_t x = merge_fetch(id_cur, sl_cur, lane);
+        id_cur = id_nxt;
+        if (v + 2u < v_hi) id_nxt = fetch_item(d, v + 2u, lane);
+        if (v + 1u < v_hi) sl_cur = fetch_slot(d, FX(id_cur, 17), lane);
+        const ItemFetch it = decode_item(d, x, lane, n, q0, q1);
+        if (it.slot == ITEM_UNUSED) break;
+        if (it.id >= route_base) continue;
+        const uint32_t pi0 = PROF_NOW();
+        (void)pi0; ++p_items;
+        if (it.id < d.n_bld) {
+            if (it.aux == ESIM_SCHOOL) continue;                              // School::find_exposures works per room
+            // first 64 residents and workers and their words: both lists' loads are in flight together
+            const uint32_t n_res = it.a_hi - it.a_lo, n_wrk = it.b_hi - it.b_lo;
+            uint32_t rm = 0u, wm = 0u, rw = 0u, ww = 0u;
+            if (lane < n_res) rm = d.res_idx ? d.res_idx[it.a_lo + lane] : it.a_lo + lane;
+            if (lane < n_wrk) wm = d.wrk_idx[it.b_lo + lane];
+            if (lane < n_res) rw = d.cit[rm];
+            if (lane < n_wrk) ww = d.cit[wm];
+            const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws);
+            __builtin_amdgcn_wave_barrier();
+            // Household / Workplace::find_exposures: every registered occupant (building.rs:202-204,278-280)
+            const UnitSrc src = { it.slot, it.link, FX(x, 7) };
+            list_or_units(d, ctrl, sm, ws, d.res_idx, it.a_lo, it.a_hi, src, lane, 0u, S, t0, true, rm, rw);
+            list_or_units(d, ctrl, sm, ws, d.wrk_idx, it.b_lo, it.b_hi, src, lane, 1u, S, t0, true, wm, ww);
+        } else {
+            const uint32_t n_mem = it.a_hi - it.a_lo;
+            uint32_t mm = 0u, mw = 0u;
+            if (lane < n_mem) mm = d.room_idx[it.a_lo + lane];
+            school_counts(d, it.link, lane, n, q0, q1, ws);
+            if (lane < n_mem) mw = d.cit[mm];
+            const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws);
+            __builtin_amdgcn_wave_barrier();
+            // School::find_exposures: the room once per infected in it (building.rs:494-522)
+            const UnitSrc src = { it.slot, it.link, FX(x, 7) };
+            list_or_units(d, ctrl, sm, ws, d.room_idx, it.a_lo, it.a_hi, src, lane, 2u, S, t0, true, mm, mw);
+        }
+        __builtin_amdgcn_wave_barrier();
+        { const uint32_t dt = PROF_NOW() - pi0; p_item_max = dt > p_item_max ? dt : p_item_max; }
+    }
+    const uint32_t pt2 = PROF_NOW();
+    // (2) routes of <= 64 riders: one wavefront per (route, bus step) with an Infected rider; rank by (Philox key, id)
+    // with shuffles, buses are runs of bus_capacity ranks (simulator.rs:362-388)
+    const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
+    // Wavefront w of k_chunk_marks left pair_cnt[w] pairs in its own stretch of the list.  They are dealt out so that the
+    // k-th pair of w goes to wavefront (w + k * PAIR_SPREAD) mod n_waves: here lane k looks at the stretch it may have
+    // been dealt from, and the wavefront then takes the pairs that exist one by one.
+    for (uint32_t k0 = 0; k0 < K; k0 += 64u) {
+        if (k0) {                                                             // (beyond the 64 looked at up front: many Infected)
+            const uint32_t kk = k0 + lane;
+            have = false;
+            if (kk < K) {
+                const uint32_t src = (wave + n_waves - (uint32_t)(((unsigned long long)kk * PAIR_SPREAD) % n_waves)) % n_waves;
+                have = kk < d.pair_cnt[src];
+                code_l = d.route_pairs[(size_t)src * K + kk];
+            }
+            if (have) { const uint32_t r = code_l >> 7; off_l = d.route_off[r]; sz_l = d.route_off[r + 1] - off_l; }
+        }
+        unsigned long long todo = __ballot(have);
+        while (todo) {
+        const int src_lane = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const uint32_t code = __shfl(code_l, src_lane, 64), off = __shfl(off_l, src_lane, 64), sz = __shfl(sz_l, src_lane, 64);
+        const uint32_t j = code & 127u;
+        const uint32_t s = t0 + j, mask = sm.dec[j].mask;
+        uint32_t c = 0, w = 0, key = 0;
+        bool inf = false;
+        if (lane < sz) {
+            c = d.route_riders[off + lane];
+            w = d.cit[c];
+            inf = status_of(CW_TE(w), s, d.exposed_time, d.infected_time) == ESIM_INFECTED;
+            key = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
+        }
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < sz; ++i) {
+            const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)i);   // i is uniform: a scalar broadcast
+            rank += ki < key || (ki == key && i < lane);                     // ids ascend with the lane
+        }
+        const uint32_t bus = rank / d.bus_capacity;
+        // Infected riders on my bus: one ballot per bus of the route
+        const unsigned long long inf_m = __ballot(inf);
+        uint32_t k = 0;
+        const uint32_t n_bus = (sz + d.bus_capacity - 1u) / d.bus_capacity;
+        for (uint32_t b = 0; b < n_bus; ++b) {
+            const unsigned long long on_b = __ballot(lane < sz && bus == b);
+            if (bus == b) k = (uint32_t)__popcll(on_b & inf_m);
+        }
+        if (lane < sz && k) {
+            const uint32_t te = CW_TE(w);
+            if (!(w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_FLAGS)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE))) {   // not exposed before this bus
+                const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
+                if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
+            }
+        }
+        }
+    }
+    const uint32_t pt3 = PROF_NOW();
+#ifndef ESIM_PROFILE_UNITS
+    PROF_PUT(d, 0, pt0); PROF_PUT(d, 1, pt1); PROF_PUT(d, 2, pt2); PROF_PUT(d, 3, pt3);   // start, after preamble, after items, end
+    PROF_PUT(d, 4, p_items); PROF_PUT(d, 5, p_item_max);
+#endif
+    (void)pt0; (void)pt1; (void)pt2; (void)pt3; (void)p_items; (void)p_item_max;
+}
+
+// The deferred units of long member lists, dealt to the wavefronts round-robin.
+// Then the routes of more than 64 riders: one workgroup per (route, bus step), ranks through LDS.
+__global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
+{
+    __shared__ ChunkShared sm;
+    __shared__ WaveScratch wsc[TPB / 64];
+    __shared__ RouteShared rs;
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t t0 = ctrl->chunk_t0, n = ctrl->chunk_ok;
+    if (!ctrl->chunk_parallel || n == 0u) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    const uint32_t pu0 = PROF_NOW();
+    uint32_t pu_n = 0u, pu_max = 0u, pu_it = 0u;
+    // queue `wave & 63`, every (n_waves / 64)-th unit of it
+    const uint32_t qr = wave & (SUBQ - 1u), first = wave / SUBQ, step = n_waves / SUBQ;
+    const uint32_t n_units = step ? min(ld(&d.hot[(HOT_UNITS + qr) * HOT_STRIDE]), d.unit_qcap) : 0u;
+    const uint32_t n_pairs = min(ld(&d.hot[HOT_BIGPAIRS * HOT_STRIDE]), 2u * d.items_cap);
+    if (__syncthreads_or(first < n_units) == 0 && n_pairs == 0u) return;
+    for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
+    for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
+    __syncthreads();
+    WaveScratch &ws = wsc[threadIdx.x >> 6];
+    const uint32_t *q_words = reinterpret_cast<const uint32_t *>(d.units + (size_t)qr * d.unit_qcap);
+    const Decision q0 = lane < n ? sm.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
+    const Decision q1 = 64u + lane < n ? sm.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
+    // Per unit: its record (lanes 0..7 of one register); then, together, the slot's interval records, the school's, and the
+    // ids of the first members its pairs touch; then those members' words.  The record of the unit after next and the
+    // second stage of the next are in flight while this one draws.
+    auto unit_words = [&](uint32_t q) -> uint32_t { return lane < 8u ? q_words[(size_t)q * 8u + lane] : 0u; };
+    auto member_id = [&](uint32_t u) -> uint32_t {
+        const uint32_t code = FX(u, 4), kind = code >> 30, lo = FX(u, 2), n_mem = FX(u, 3), mf = FX(u, 6);
+        if (code == UNIT_NOOP || mf + lane >= n_mem) return 0u;
+        const uint32_t *idx = kind == 2u ? d.room_idx : kind == 1u ? d.wrk_idx : d.res_idx;
+        return idx ? idx[lo + mf + lane] : lo + mf + lane;
+    };
+    const uint32_t pu1 = PROF_NOW();
+    uint32_t u_0 = 0xFFFFFFFFu, u_1 = 0xFFFFFFFFu;                            // this unit, the next (code word UNIT_NOOP: none)
+    uint32_t xs_0 = 0u, ys_0 = 0u, mid_0 = 0u;
+    if (first < n_units) u_0 = unit_words(first);
+    if (first + step < n_units) u_1 = unit_words(first + step);
+    if (first < n_units && FX(u_0, 4) != UNIT_NOOP) { xs_0 = fetch_slot(d, FX(u_0, 0), lane); ys_0 = fetch_slot(d, FX(u_0, 1), lane); mid_0 = member_id(u_0); }
+    for (uint32_t q = first; q < n_units; q += step) {
+        const uint32_t u = u_0, xs = xs_0, ys = ys_0, mid = mid_0;
+        u_0 = u_1;
+        u_1 = 0xFFFFFFFFu;
+        if (q + 2u * step < n_units) u_1 = unit_words(q + 2u * step);
+        if (q + step < n_units && FX(u_0, 4) != UNIT_NOOP) { xs_0 = fetch_slot(d, FX(u_0, 0), lane); ys_0 = fetch_slot(d, FX(u_0, 1), lane); mid_0 = member_id(u_0); }
+        const uint32_t code = FX(u, 4);
+        if (code == UNIT_NOOP) continue;
+        const uint32_t pui = PROF_NOW();
+        ++pu_n;
+        const uint32_t kind = code >> 30, p_lo = code & 0x3FFFFFFFu, slot = FX(u, 0), link = FX(u, 1), lo = FX(u, 2), n_mem = FX(u, 3), own = FX(u, 5), mf = FX(u, 6);
+        const uint32_t mw = (mf + lane < n_mem) ? d.cit[mid] : 0u;
+        uint32_t c0, c1;
+        item_counts(d, xs, slot, lane, n, q0, q1, c0, c1);
+        if (lane < n) c0 += iv_present(own, lane, q0);
+        if (64u + lane < n) c1 += iv_present(own, 64u + lane, q1);
+        if (kind == 2u) {
+            uint32_t s0 = 0u, s1 = 0u;
+            if (link != 0xFFFFFFFFu) item_counts(d, ys, link, lane, n, q0, q1, s0, s1);
+            ws.sch[lane] = s0;
+            if (lane < FREE_MAX - 64u) ws.sch[64u + lane] = s1;
+        }
+        const uint32_t *idx = kind == 2u ? d.room_idx : kind == 1u ? d.wrk_idx : d.res_idx;
+        const uint32_t S = item_steps_regs(c0, c1, lane, ws);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t pairs = n_mem * S;
+        member_pairs(d, ctrl, sm, ws, idx, lo, p_lo, min(pairs, p_lo + UNIT_PAIRS), lane, kind, S, t0, true, mid, mw, mf);
+        __builtin_amdgcn_wave_barrier();
+        { const uint32_t dt = PROF_NOW() - pui; pu_max = dt > pu_max ? dt : pu_max; pu_it += (min(pairs, p_lo + UNIT_PAIRS) - p_lo + 63u) / 64u; }
+    }
+    const uint32_t pu2 = PROF_NOW();
+#ifdef ESIM_PROFILE_UNITS
+    PROF_PUT(d, 0, pu0); PROF_PUT(d, 1, pu1); PROF_PUT(d, 2, pu2); PROF_PUT(d, 4, pu_n); PROF_PUT(d, 5, pu_max); PROF_PUT(d, 7, pu_it);
+#endif
+    (void)pu0; (void)pu1; (void)pu2; (void)pu_n; (void)pu_max; (void)pu_it;
+    const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
+    for (uint32_t q = blockIdx.x; q < n_pairs; q += gridDim.x) {
+        const uint32_t code = d.route_pairs_big[q], r = code >> 7, j = code & 127u;
+        const uint32_t off = d.route_off[r], sz = d.route_off[r + 1] - off;
+        const uint32_t s = t0 + j, mask = sm.dec[j].mask;
+        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
+            const uint32_t c = d.route_riders[off + i];
+            rs.s_key[i] = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
+            rs.s_inf[i] = status_of(CW_TE(d.cit[c]), s, d.exposed_time, d.infected_time) == ESIM_INFECTED ? 1 : 0;
+        }
+        for (uint32_t i = threadIdx.x; i < sz / d.bus_capacity + 1u; i += TPB) rs.s_cnt[i] = 0u;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
+            const uint32_t ki = rs.s_key[i];
+            uint32_t rank = 0;
+            for (uint32_t qq = 0; qq < sz; ++qq) { const uint32_t kq = rs.s_key[qq]; rank += kq < ki || (kq == ki && qq < i); }
+            const uint32_t bus = rank / d.bus_capacity;
+            rs.s_bus[i] = (uint16_t)bus;
+            if (rs.s_inf[i]) atomicAdd(&rs.s_cnt[bus], 1u);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
+            const uint32_t k = rs.s_cnt[rs.s_bus[i]];
+            if (!k) continue;
+            const uint32_t c = d.route_riders[off + i];
+            const uint32_t w = d.cit[c], te = CW_TE(w);
+            if (w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_FLAGS)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE)) continue;   // exposed before this bus
+            const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
+            if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
+        }
+        __syncthreads();
+    }
+}
+
+// Exposures per step (statistics.rs:181) from the final citizen words -- the many-workgroup form, for chunks with many new
+// exposures (k_chunk_books does it itself otherwise).
+__global__ __launch_bounds__(TPB) void k_chunk_count(Dev d)
+{
+    if (!d.ctrl->chunk_parallel || d.ctrl->chunk_ok == 0u) return;
+    const uint32_t tid = blockIdx.x * TPB + threadIdx.x, r = tid & (SUBQ - 1u), step = (gridDim.x * TPB) / SUBQ;
+    const uint32_t n_new = min(ld(&d.hot[(HOT_NEWEXP + r) * HOT_STRIDE]), d.newexp_cap);
+    const uint32_t *list = d.newexp + (size_t)r * d.newexp_cap;
+    // (exp_step of the chunk's steps is zero from reset / from nobody having written it: steps are visited once)
+    for (uint32_t i = tid / SUBQ; i < n_new; i += step) {
+        const uint32_t w = d.cit[list[i]];
+        const uint32_t s = CW_TE(w) - TE_BIAS;
+        atomicAdd(&d.exp_step[2u * s + ((w & CW_BUS_EXPOSED) ? 1u : 0u)], 1u);
+    }
+}
+
+// The chunk's exposures enter the log grouped by step (after k_batch_finish wrote the offsets); the hash map and
+// the count vectors are emptied for the next chunk.
+__global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d)
+{
+    Ctrl *ctrl = d.ctrl;
+    if (ctrl->chunk_done == 0u) return;
+    // (the chunk as k_chunk_books noted it down: by now the control block may describe the next one)
+    const uint32_t t0 = ctrl->prev_t0;
+    const uint32_t n_items = min(ctrl->prev_n_items, d.items_cap);
+    {
+        const uint32_t tid = blockIdx.x * TPB + threadIdx.x, r = tid & (SUBQ - 1u), step = (gridDim.x * TPB) / SUBQ;
+        const uint32_t n_new = min(d.hot[(HOT_PREV_NEWEXP + r) * HOT_STRIDE], d.newexp_cap);
+        const uint32_t *list = d.newexp + (size_t)r * d.newexp_cap;
+        for (uint32_t i = tid / SUBQ; i < n_new; i += step) {
+            const uint32_t m = list[i];
+            const uint32_t te = CW_TE(d.cit[m]);
+            d.log[d.log_off[te] + atomicAdd(&d.cursor[te - TE_BIAS - t0], 1u)] = m;
+        }
+    }
+    // the hash slots (and spilled count vectors) of the ids that were handed out: a thread per (wavefront of k_chunk_marks,
+    // k-th id of its range), so that the whole clean-up is three dependent loads deep
+    const uint32_t per_wave = ctrl->prev_per_wave, n_mw = per_wave ? n_items / per_wave : 0u;
+    const uint32_t tid = blockIdx.x * TPB + threadIdx.x, nth = gridDim.x * TPB;
+    for (uint32_t i = tid; i < n_mw * per_wave; i += nth) {
+        const uint32_t w = i / per_wave, k = i - w * per_wave;
+        if (k >= d.used_cnt[w]) continue;
+        const uint32_t h = d.hitems[i];
+        if (h == ITEM_UNUSED) continue;
+        const uint32_t state = d.slot_state[h];
+        if (state > ITEM_RECS && d.item_rec[i].id < d.n_bld + d.n_room)       // somebody spilled into the per-step counters
+            for (uint32_t j = 0; j < FREE_MAX; ++j) d.vec[(size_t)h * FREE_MAX + j] = 0u;
+        d.hkey[h] = HKEY_EMPTY;
+        if (state) d.slot_state[h] = 0u;
+    }
+}
+
+// ----------------------------------------------------------------------------- k_batch_finish
+// The books of a pipelined chunk [t0, t0+n): census (simulator.rs:178) by sliding the Exposed / Infected
+// windows over the exposure histogram, the StatisticEntry of every step (statistics.rs:208-215, adjusted
+// by citizen_exposed :275-287), hist / log offsets, and the control block as it stands after the chunk.
+// (body shared by the two launch forms below)
+// e: this chunk's exposure counts [2 * step of the chunk + (bus ? 1 : 0)] when the caller holds them (else d.exp_step has them);
+// lo_out: receives the first log position of every step of the chunk.
+__device__ __forceinline__ void batch_finish_body(const Dev &d, uint32_t t0, uint32_t n, const uint32_t *e = nullptr, uint32_t *lo_out = nullptr)
+{
+    __shared__ uint32_t P[BF_WIN + 1];                 // P[i + 1] = sum of H[0..i], P[0] = 0
+    __shared__ uint32_t wtmp[FIN_TPB / 64];
+    __shared__ uint32_t n_eff_s;
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t tid = threadIdx.x;
+    const int et = (int)d.exposed_time, it = (int)d.infected_time;
+    const int base_idx = (int)(t0 + TE_BIAS) - et - 1 - it;              // lowest histogram entry any census of the chunk reads
+    // H[i] = citizens exposed in "step" base_idx + i: the histogram before the chunk, this chunk's exposure counters inside it
+    {
+        const int k = base_idx + (int)tid;
+        uint32_t h = 0;
+        if (k >= (int)(t0 + TE_BIAS)) { const uint32_t j = (uint32_t)(k - (int)(t0 + TE_BIAS)); if (j < n) h = e ? e[2u * j] + e[2u * j + 1u] : d.exp_step[2u * (t0 + j)] + d.exp_step[2u * (t0 + j) + 1u]; }
+        else if (k >= 0) h = d.hist[k];
+        P[tid + 1] = h;
+        if (tid == 0) { P[0] = 0u; n_eff_s = n; }
+    }
+    __syncthreads();
+    block_scan_1024(P + 1, wtmp);
+    const uint32_t S0 = ctrl->n_susceptible, V = ctrl->n_vaccinated, run0 = d.log_off[t0 + TE_BIAS];
+    const int top0 = (int)(t0 + TE_BIAS) - base_idx;                      // index of hist[t0 + TE_BIAS] in H
+    esim_step_result r;
+    uint32_t exps = 0;
+    if (tid < n) {
+        const uint32_t s = t0 + tid;
+        const int ts = top0 + (int)tid;                                   // index of this step's own entry
+        exps = P[ts + 1] - P[ts];
+        const uint32_t S = S0 - (P[ts] - P[top0]);                         // Susceptible before this step's exposures
+        const uint32_t E = P[ts] - P[ts - et];                             // exposed in steps s - et .. s - 1 (census precedes exposures)
+        const uint32_t I = P[ts - et] - P[ts - et - 1 - it];
+        r.time_step = s;
+        if (exps > S) ctrl->error = (uint32_t)(-ESIM_ESIM);               // citizen_exposed underflow, statistics.rs:275-287
+        r.susceptible = S - exps; r.exposed = E + exps; r.infected = I;
+        r.recovered = d.n - S - V - E - I; r.vaccinated = V;
+        r.exposures_building = e ? e[2u * tid] : d.exp_step[2u * s]; r.exposures_bus = e ? e[2u * tid + 1u] : d.exp_step[2u * s + 1u];
+        if (e) { d.exp_step[2u * s] = r.exposures_building; d.exp_step[2u * s + 1u] = r.exposures_bus; }
+        if (lo_out) lo_out[tid] = run0 + (P[ts] - P[top0]);
+        r.lockdown = d.dec[tid + 1u].lockdown; r.vaccination_active = 0u; r.mask_status = d.dec[tid + 1u].mask;
+        r.n_riders = d.dec[tid].bus_dir ? d.n_pt : 0u; r.vaccinated_now = 0u; r.eligible_count = 0u;
+        r.disease_exists = (r.exposed != 0u || r.infected != 0u || r.susceptible != 0u) ? 1u : 0u;   // statistics.rs:289-291
+        r.reserved = 0u;
+        if (!r.disease_exists && ctrl->stop_when_done) atomicMin(&n_eff_s, tid + 1u);
+    }
+    __syncthreads();
+    const uint32_t n_eff = n_eff_s;
+    if (tid < n_eff) {
+        const uint32_t s = t0 + tid;
+        const int ts = top0 + (int)tid;
+        d.hist[s + TE_BIAS] = exps;
+        d.log_off[s + TE_BIAS + 1u] = run0 + (P[ts + 1] - P[top0]);
+        if (s <= d.max_steps) d.records[s] = r;
+    }
+    if (tid == 0) {
+        ctrl->n_susceptible = S0 - (P[top0 + (int)n_eff] - P[top0]);
+        ctrl->log_len = run0 + (P[top0 + (int)n_eff] - P[top0]);
+        ctrl->t = t0 + n_eff; ctrl->steps_done = t0 + n_eff - 1u;
+        if (n_eff < n) ctrl->finished = 1u;
+        ctrl->lockdown = d.dec[n_eff].lockdown; ctrl->mask = d.dec[n_eff].mask;
+        ctrl->at_work = d.dec[n_eff - 1u].at_work; ctrl->bus_dir = d.dec[n_eff - 1u].bus_dir;
+        // ring slots: only the last step's marks stay (the next exposure pass clears them)
+        const uint32_t keep = (t0 + n - 1u) & (MARK_SLOTS - 1u);
+        for (uint32_t z = 0; z < MARK_SLOTS; ++z)
+            if (z != keep) { ctrl->n_touched_bld[z] = 0u; ctrl->n_touched_room[z] = 0u; ctrl->n_touched_route[z] = 0u; ctrl->n_touched_route_big[z] = 0u; }
+    }
+}
+
+__global__ __launch_bounds__(FIN_TPB) void k_batch_finish(Dev d, uint32_t t0, uint32_t n)
+{
+    batch_finish_body(d, t0, n);
+}
+
+// The books of a one-pass chunk, in ONE workgroup so that nothing but kernel boundaries of the wide kernels is left on
+// the chunk's critical path (a kernel boundary costs ~4.5 us here, and these steps are small):
+//   exposures per step (statistics.rs:181) from the final citizen words of the newly exposed
+//   census, records, histogram, log offsets, control block (batch_finish_body)
+//   [scatter] the new log entries in step order; hash slots of the chunk's items emptied
+//   [next]    the census ahead and the decisions of the NEXT chunk (k_future + k_decide)
+// It takes (t0, n) from the control block, so that the host can enqueue chunk after chunk without waiting; chunk_done tells
+// k_chunk_scatter (the many-workgroup form of [scatter], used while many citizens are Infected) that the books were written.
+__global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int do_next, uint32_t max_ahead, uint32_t limit_t)
+{
+    __shared__ uint32_t e_cnt[2 * FREE_MAX];
+    __shared__ uint32_t lo_s[FREE_MAX], cur_s[FREE_MAX];
+    __shared__ uint32_t win[BF_WIN];
+    __shared__ uint32_t wtmp[FIN_TPB / 64];
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t tid = threadIdx.x;
+    if (!ctrl->chunk_parallel || ctrl->chunk_ok == 0u) {
+        if (tid == 0) ctrl->chunk_done = 0u;
+        // a sharded burst all-reduces buffer F in place before every chunk: it must hold THIS shard's census again, whether
+        // or not the chunk ran
+        if (do_next == 2) future_body(d, max_ahead, limit_t, win, wtmp);
+        return;
+    }
+    const uint32_t t0 = ctrl->chunk_t0, n = ctrl->chunk_ok;
+    const uint32_t n_items = min(ld(&ctrl->n_items), d.items_cap);
+    if (tid < 2u * FREE_MAX) e_cnt[tid] = 0u;
+    if (tid < FREE_MAX) cur_s[tid] = 0u;
+    __syncthreads();
+    // sub-list `thread & 63` of the newly exposed, every 16th entry of it
+    const uint32_t r = tid & (SUBQ - 1u);
+    const uint32_t n_new = min(ld(&d.hot[(HOT_NEWEXP + r) * HOT_STRIDE]), d.newexp_cap);
+    const uint32_t *list = d.newexp + (size_t)r * d.newexp_cap;
+    if (fused) {
+        for (uint32_t i = tid / SUBQ; i < n_new; i += FIN_TPB / SUBQ) {
+            const uint32_t w = d.cit[list[i]];
+            atomicAdd(&e_cnt[2u * (CW_TE(w) - TE_BIAS - t0) + ((w & CW_BUS_EXPOSED) ? 1u : 0u)], 1u);
+        }
+    } else if (tid < 2u * n) e_cnt[tid] = d.exp_step[2u * t0 + tid];           // k_chunk_count made them
+    __syncthreads();
+    batch_finish_body(d, t0, n, e_cnt, lo_s);
+    if (!fused) {
+        // k_chunk_scatter runs after this kernel, i.e. after the next chunk's decisions have reset what it reads: keep a copy
+        if (tid < SUBQ) d.hot[(HOT_PREV_NEWEXP + tid) * HOT_STRIDE] = n_new;   // (thread r < 64 read sub-list r's length above)
+        if (tid == 0) { ctrl->prev_t0 = t0; ctrl->prev_n_items = n_items; ctrl->prev_per_wave = ld(&ctrl->items_per_wave); }
+    }
+    if (tid == 0) ctrl->chunk_done = 1u;
+    if (tid < 64u) {
+        // totals of the split lists, for esim_debug_counters
+        uint32_t a = ld(&d.hot[(HOT_NEWEXP + tid) * HOT_STRIDE]), b = ld(&d.hot[(HOT_UNITS + tid) * HOT_STRIDE]);
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if (tid == 0) { ctrl->n_newexp = a; ctrl->n_units = b; ctrl->n_route_pairs_big = ld(&d.hot[HOT_BIGPAIRS * HOT_STRIDE]); }
+    }
+    __syncthreads();
+    if (fused) {
+        for (uint32_t i = tid / SUBQ; i < n_new; i += FIN_TPB / SUBQ) {
+            const uint32_t m = list[i];
+            const uint32_t j = CW_TE(d.cit[m]) - TE_BIAS - t0;
+            d.log[lo_s[j] + atomicAdd(&cur_s[j], 1u)] = m;
+        }
+        // the ids each wavefront of k_chunk_marks handed out: thread t looks after the wavefronts t, t + 1024, ...; all loads
+        // of a round are in flight together (this loop is nothing but memory latency)
+        const uint32_t per_wave = ld(&ctrl->items_per_wave), n_mw = per_wave ? n_items / per_wave : 0u;
+        for (uint32_t w0 = tid; w0 < n_mw; w0 += 4u * FIN_TPB) {
+            uint32_t used[4], h[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { const uint32_t w = w0 + (uint32_t)a * FIN_TPB; used[a] = w < n_mw ? d.used_cnt[w] : 0u; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) h[a][k] = (uint32_t)k < used[a] ? d.hitems[(w0 + (uint32_t)a * FIN_TPB) * per_wave + (uint32_t)k] : ITEM_UNUSED;
+            uint32_t st[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) st[a][k] = h[a][k] != ITEM_UNUSED ? d.slot_state[h[a][k]] : 0u;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const uint32_t base = (w0 + (uint32_t)a * FIN_TPB) * per_wave;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t hs = h[a][k], state = st[a][k];
+                    if (hs == ITEM_UNUSED) continue;
+                    if (state > ITEM_RECS && d.item_rec[base + (uint32_t)k].id < d.n_bld + d.n_room)   // somebody spilled into the per-step counters
+                        for (uint32_t j = 0; j < FREE_MAX; ++j) d.vec[(size_t)hs * FREE_MAX + j] = 0u;
+                    d.hkey[hs] = HKEY_EMPTY;
+                    if (state) d.slot_state[hs] = 0u;
+                }
+                for (uint32_t k = 4u; k < used[a]; ++k) {                     // (more than four ids per wavefront: many Infected)
+                    const uint32_t hs = d.hitems[base + k];
+                    if (hs == ITEM_UNUSED) continue;
+                    const uint32_t state = d.slot_state[hs];
+                    if (state > ITEM_RECS && d.item_rec[base + k].id < d.n_bld + d.n_room)
+                        for (uint32_t j = 0; j < FREE_MAX; ++j) d.vec[(size_t)hs * FREE_MAX + j] = 0u;
+                    d.hkey[hs] = HKEY_EMPTY;
+                    if (state) d.slot_state[hs] = 0u;
+                }
+            }
+        }
+    }
+    if (do_next) {
+        // 1: the next chunk's census ahead and decisions; 2: the census ahead only (sharded runs all-reduce it before deciding)
+        __syncthreads();
+        future_body(d, max_ahead, limit_t, win, wtmp);
+        __syncthreads();
+        if (do_next == 1 && tid < 64u) decide_body(d, max_ahead, limit_t, 1);
+    }
+}
