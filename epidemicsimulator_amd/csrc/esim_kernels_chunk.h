@@ -1054,6 +1054,9 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
         // k_chunk_scatter runs after this kernel, i.e. after the next chunk's decisions have reset what it reads: keep a copy
         if (tid < SUBQ) d.hot[(HOT_PREV_NEWEXP + tid) * HOT_STRIDE] = n_new;   // (thread r < 64 read sub-list r's length above)
         if (tid == 0) { ctrl->prev_t0 = t0; ctrl->prev_n_items = n_items; ctrl->prev_per_wave = ld(&ctrl->items_per_wave); }
+        // ... and start its per-step write cursors from zero: the scatter of the chunk before this one ran after the
+        // decision step that last cleared them
+        if (tid < FREE_MAX) d.cursor[tid] = 0u;
     }
     if (tid == 0) ctrl->chunk_done = 1u;
     if (tid < 64u) {

@@ -353,6 +353,18 @@ def random_population(seed, n=700, n_areas=5, n_buildings=90, n_schools=3, rooms
                       building_type=b_type, room_building=room_bld, seeds=seeds, n_areas=n_areas)
 
 
+def test_many_infected_several_chunks_per_call():
+    # found by tools/fuzz_parity.py (seed 1124): with more than 1024 Infected the chunk's log scatter is a kernel of its
+    # own that runs AFTER the next chunk's decisions; two such chunks in one call must not share write cursors.  Big
+    # buildings (more Infected per building than an item has records => the spilled per-step counters), a single school
+    # room of ~900, short chunks (exposed_time 30), a lockdown threshold that toggles.
+    pop = random_population(1124, n=2500, n_areas=12, n_buildings=40, n_schools=1, rooms_per_school=1)
+    params = dict(exposure_chance=0.0005, seed=587668745022, vaccination_threshold=2.0, lockdown_threshold=0.01,
+                  mask_pt_threshold=0.005, mask_everywhere_threshold=0.2, bus_capacity=2, exposed_time=30, infected_time=336)
+    for block in (50, 160, 500):
+        run_both(pop, 500, check_state_every=block, small_limits=("tp",), **params)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_populations_all_paths(seed):
     pop = random_population(seed)
