@@ -170,6 +170,24 @@ def main():
                          "wall_algorithmic_GBs": ALGO_BYTES_PER_CITIZEN_STEP * n_total * steps / elapsed / 1e9},
             "final_record": {k: int(rec[k][-1]) for k in ("time_step", "susceptible", "exposed", "infected", "recovered", "vaccinated")},
         }
+        if world == 1:
+            # the whole run against records the CPU oracle produced offline for this preset (tests/golden/make_preset_golden.py):
+            # every 50th step up to the steps run here
+            gpath = os.path.join(ROOT, "tests", "golden", "oracle_%s_5000.json" % args.preset)
+            if os.path.exists(gpath):
+                gold = json.load(open(gpath))
+                if gold["seed"] == int(params.seed):
+                    compared = 0
+                    for want in gold["records"]:
+                        if want["time_step"] > steps:
+                            break
+                        got = rec[want["time_step"] - 1]
+                        for f in ("susceptible", "exposed", "infected", "recovered", "vaccinated"):
+                            if int(got[f]) != want[f]:
+                                raise SystemExit("bench: step %d %s = %d, the offline CPU oracle has %d (%s)"
+                                                 % (want["time_step"], f, int(got[f]), want[f], gpath))
+                        compared += 1
+                    out["golden_check"] = {"file": os.path.relpath(gpath, ROOT), "records_compared": compared, "match": True}
         if world == 1 and args.cpu_steps > 0:
             cb, orc_rec = cpu_baseline(pop, params, min(args.cpu_steps, steps))
             out["cpu_baseline"] = cb

@@ -1,6 +1,6 @@
-"""Golden records of the benchmark workload at full size: the CPU oracle on the 64 M-citizen `uk64m` preset for 5000 steps
-(about 20 minutes and 6 GB on one core).  Writes tests/golden/oracle_uk64m_5000.json: every 50th record and the last.
-  python tests/golden/make_uk64m_golden.py"""
+"""Golden records of the benchmark workloads at full size: the CPU oracle on a synthetic preset for 5000 steps (uk64m: about
+20 minutes and 6 GB on one core).  Writes tests/golden/oracle_<preset>_5000.json: every 50th record and the last.
+  python tests/golden/make_uk64m_golden.py [preset]"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,8 @@ import _oracle
 from epidemicsimulator_amd import Population, _lib
 
 t0 = time.time()
-pop = Population.synthetic("uk64m")
+preset = sys.argv[1] if len(sys.argv) > 1 else "uk64m"
+pop = Population.synthetic(preset)
 ep = _lib.default_params(max_steps=5000)
 orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
 print("population %.0f s" % (time.time() - t0), flush=True)
@@ -24,6 +25,6 @@ while done < 5000:
     rows[-1]["exposures_bus_block"] = int(r["exposures_bus"].sum())
     if done % 500 == 0:
         print(done, rows[-1], "%.0f s" % (time.time() - t0), flush=True)
-json.dump({"preset": "uk64m", "seed": int(ep.seed), "steps": 5000, "every": 50, "records": rows},
-          open(os.path.join(ROOT, "tests", "golden", "oracle_uk64m_5000.json"), "w"), indent=0)
+json.dump({"preset": preset, "seed": int(ep.seed), "steps": 5000, "every": 50, "records": rows},
+          open(os.path.join(ROOT, "tests", "golden", "oracle_%s_5000.json" % preset), "w"), indent=0)
 print("done %.0f s" % (time.time() - t0))

@@ -353,6 +353,23 @@ def random_population(seed, n=700, n_areas=5, n_buildings=90, n_schools=3, rooms
                       building_type=b_type, room_building=room_bld, seeds=seeds, n_areas=n_areas)
 
 
+def test_one_huge_workplace_overflows_a_unit_queue():
+    # 9000 citizens who all work in ONE building: its worker list is 9000 x 32 work steps = 288 000 (member, step) pairs
+    # per chunk = 1125 units of 256, more than one unit queue holds (1024): the producing wavefront has to draw the
+    # list itself; households of four, a second area so that half of the workers fail the same-area filter
+    n = 9000
+    home = (np.arange(n, dtype=np.uint32) // 4)
+    n_home = int(home.max()) + 1
+    work = np.full(n, n_home, np.uint32)
+    area = np.concatenate([(np.arange(n_home) % 2).astype(np.uint32), [0]]).astype(np.uint32)
+    btype = np.concatenate([np.zeros(n_home, np.uint8), [_lib.WORKPLACE]]).astype(np.uint8)
+    flags = (np.arange(n) % 3 == 0).astype(np.uint8) * 2
+    pop = Population(home_building=home, work_building=work, flags=flags, building_area=area, building_type=btype,
+                     seeds=np.arange(0, 40, 2, dtype=np.uint32), n_areas=2)
+    run_both(pop, 250, check_state_every=125, small_limits=("tp", None), exposure_chance=0.00002, seed=99,
+             vaccination_threshold=2.0, lockdown_threshold=2.0)
+
+
 def test_many_infected_several_chunks_per_call():
     # found by tools/fuzz_parity.py (seed 1124): with more than 1024 Infected the chunk's log scatter is a kernel of its
     # own that runs AFTER the next chunk's decisions; two such chunks in one call must not share write cursors.  Big
