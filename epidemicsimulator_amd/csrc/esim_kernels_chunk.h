@@ -1026,6 +1026,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
     __shared__ uint32_t wtmp[FIN_TPB / 64];
     Ctrl *ctrl = d.ctrl;
     const uint32_t tid = threadIdx.x;
+    const uint32_t pb0 = PROF_NOW();
     if (!ctrl->chunk_parallel || ctrl->chunk_ok == 0u) {
         if (tid == 0) ctrl->chunk_done = 0u;
         // a sharded burst all-reduces buffer F in place before every chunk: it must hold THIS shard's census again, whether
@@ -1049,7 +1050,9 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
         }
     } else if (tid < 2u * n) e_cnt[tid] = d.exp_step[2u * t0 + tid];           // k_chunk_count made them
     __syncthreads();
+    const uint32_t pb1 = PROF_NOW();
     batch_finish_body(d, t0, n, e_cnt, lo_s);
+    const uint32_t pb2 = PROF_NOW();
     if (!fused) {
         // k_chunk_scatter runs after this kernel, i.e. after the next chunk's decisions have reset what it reads: keep a copy
         if (tid < SUBQ) d.hot[(HOT_PREV_NEWEXP + tid) * HOT_STRIDE] = n_new;   // (thread r < 64 read sub-list r's length above)
@@ -1112,11 +1115,16 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
             }
         }
     }
+    const uint32_t pb3 = PROF_NOW();
     if (do_next) {
         // 1: the next chunk's census ahead and decisions; 2: the census ahead only (sharded runs all-reduce it before deciding)
         __syncthreads();
         future_body(d, max_ahead, limit_t, win, wtmp);
         __syncthreads();
+        const uint32_t pb4 = PROF_NOW();
         if (do_next == 1 && tid < 64u) decide_body(d, max_ahead, limit_t, 1);
+        BOOKS_PROF(d, 4, pb4 - pb3);
     }
+    BOOKS_PROF(d, 0, pb1 - pb0); BOOKS_PROF(d, 1, pb2 - pb1); BOOKS_PROF(d, 2, pb3 - pb2); BOOKS_PROF(d, 3, PROF_NOW() - pb3);
+    (void)pb0; (void)pb1; (void)pb2; (void)pb3;
 }
