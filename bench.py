@@ -27,19 +27,21 @@ ALGO_BYTES_PER_CITIZEN_STEP = 26.0      # state R+W 4, flags 2, 
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
-def cpu_baseline(pop, params, steps):
-    """The CPU oracle (oracle/esim_oracle.c, single thread) timed on this host on the first `steps`
-    time steps of the same population.  A reported baseline, not the thing measured."""
+def cpu_baseline(pop, params, steps, threads):
+    """The CPU oracle (oracle/esim_oracle.c) timed on this host on the first `steps` time steps of the same population, its
+    per-citizen pass on `threads` host threads (the part the reference runs under rayon).  A reported baseline, not the
+    thing measured."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle
     orc = _oracle.Oracle(pop, _oracle.params_from_esim(params))
+    threads = orc.set_threads(threads)
     t0 = time.perf_counter()
     rec = orc.run(steps)
     dt = time.perf_counter() - t0
     orc.close()
-    return {"value": pop.n_citizens * len(rec) / dt, "unit": "citizen-timesteps/s", "cores": 1, "kind": "port",
-            "sample": "first %d time steps of the same %d-citizen population, single-thread oracle/esim_oracle.c, %.1f s"
-                      % (len(rec), pop.n_citizens, dt)}, rec
+    return {"value": pop.n_citizens * len(rec) / dt, "unit": "citizen-timesteps/s", "cores": threads, "kind": "port",
+            "sample": "first %d time steps of the same %d-citizen population, oracle/esim_oracle.c with its per-citizen pass on %d "
+                      "thread(s) (bus sorting, exposures and interventions serial), %.1f s" % (len(rec), pop.n_citizens, threads, dt)}, rec
 
 
 def main():
@@ -48,7 +50,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5000)
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--preset", default="uk64m", help="synthetic population preset (default: the benchmark workload)")
-    ap.add_argument("--cpu-steps", type=int, default=24, help="time steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=48, help="time steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = all this process may use)")
     ap.add_argument("--timing-stride", type=int, default=16, help="bracket the per-citizen kernels with HIP events every n-th step")
     ap.add_argument("--small-limit", type=int, default=None, help="override the persistent-kernel hand-over threshold (Infected citizens)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
@@ -189,7 +192,8 @@ def main():
                         compared += 1
                     out["golden_check"] = {"file": os.path.relpath(gpath, ROOT), "records_compared": compared, "match": True}
         if world == 1 and args.cpu_steps > 0:
-            cb, orc_rec = cpu_baseline(pop, params, min(args.cpu_steps, steps))
+            n_thr = args.cpu_threads or len(os.sched_getaffinity(0))
+            cb, orc_rec = cpu_baseline(pop, params, min(args.cpu_steps, steps), n_thr)
             out["cpu_baseline"] = cb
             for f in ("susceptible", "exposed", "infected", "recovered", "vaccinated"):
                 if not (orc_rec[f] == rec[f][:len(orc_rec)]).all():

@@ -11,6 +11,9 @@
  */
 #include "esim_oracle.h"
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -133,6 +136,9 @@ struct orc_sim {
     /* per-step scratch */
     int32_t  *inf_head; uint32_t *inf_cnt; uint32_t *touched; uint32_t n_touched;
     rider_t  *riders; uint32_t n_riders;
+    int threads;               /* > 1: the per-citizen pass of a step runs on that many host threads (orc_set_threads) */
+    uint32_t *inf_list;        /* [n_cit] scratch of the threaded pass: Infected citizens not on a bus, ascending */
+    uint64_t *thr_counts;      /* [threads][8] */
     uint32_t *chosen_stamp;
     /* global state */
     uint32_t time_step;              /* StatisticsRecorder.current_time_step, statistics.rs:104 */
@@ -250,7 +256,7 @@ void orc_destroy(orc_sim *s)
     free(s->cit); free(s->bld_area); free(s->bld_type); free(s->room_bld);
     free(s->res_off); free(s->res_idx); free(s->wrk_off); free(s->wrk_idx);
     free(s->room_off); free(s->room_idx);
-    free(s->inf_head); free(s->inf_cnt); free(s->touched); free(s->riders);
+    free(s->inf_head); free(s->inf_cnt); free(s->touched); free(s->riders); free(s->inf_list); free(s->thr_counts);
     free(s->chosen_stamp);
     free(s);
 }
@@ -336,6 +342,93 @@ static int try_building_exposure(orc_sim *s, orc_record *rec, uint32_t b, uint32
     return 0;
 }
 
+/* The per-citizen pass of generate_exposures on several host threads (the reference runs it under rayon,
+ * simulator.rs:167-260).  Same result as the loop in orc_step: every citizen's tick is independent, the census is a sum,
+ * and riders / Infected are collected in ascending citizen order exactly as the sequential loop meets them. */
+static void generate_exposures_threaded(orc_sim *s, orc_record *rec, uint32_t hour, int lockdown)
+{
+    const orc_params *P = &s->P;
+    const int T = s->threads;
+    memset(s->thr_counts, 0, sizeof(uint64_t) * 8u * (size_t)T);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(T)
+#endif
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num();
+#else
+        const int t = 0;
+#endif
+        const uint32_t lo = (uint32_t)((uint64_t)s->n_cit * (uint64_t)t / (uint64_t)T);
+        const uint32_t hi = (uint32_t)((uint64_t)s->n_cit * (uint64_t)(t + 1) / (uint64_t)T);
+        uint64_t k[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (uint32_t c = lo; c < hi; ++c) {
+            citizen_t *z = &s->cit[c];
+            citizen_execute_time_step(P, z, hour, lockdown);
+            z->school_draws = 0;
+            switch (z->status) {
+            case ORC_S: k[0]++; break;
+            case ORC_E: k[1]++; break;
+            case ORC_I: k[2]++; break;
+            case ORC_R: k[3]++; break;
+            default:    k[4]++; break;
+            }
+            if (z->bus) k[5]++;
+            else if (z->status == ORC_I) k[6]++;
+        }
+        memcpy(s->thr_counts + 8u * (size_t)t, k, sizeof k);
+#ifdef _OPENMP
+#pragma omp barrier
+#endif
+        uint64_t r_off = 0, i_off = 0;
+        for (int q = 0; q < t; ++q) { r_off += s->thr_counts[8u * (size_t)q + 5]; i_off += s->thr_counts[8u * (size_t)q + 6]; }
+        for (uint32_t c = lo; c < hi; ++c) {
+            const citizen_t *z = &s->cit[c];
+            if (z->bus) {
+                rider_t *r = &s->riders[r_off++];
+                uint32_t ah = s->bld_area[z->home], aw = s->bld_area[z->work];
+                r->src = z->bus == 1 ? ah : aw;
+                r->dst = z->bus == 1 ? aw : ah;
+                uint32_t w[4];
+                philox_block(P->seed, c, s->time_step, 3, w);
+                r->key = w[0]; r->id = c; r->infected = z->status == ORC_I;
+            } else if (z->status == ORC_I) s->inf_list[i_off++] = c;
+        }
+    }
+    uint64_t n_inf = 0;
+    for (int q = 0; q < T; ++q) {
+        const uint64_t *k = s->thr_counts + 8u * (size_t)q;
+        rec->susceptible += (uint32_t)k[0]; rec->exposed += (uint32_t)k[1]; rec->infected += (uint32_t)k[2];
+        rec->recovered += (uint32_t)k[3]; rec->vaccinated += (uint32_t)k[4];
+        s->n_riders += (uint32_t)k[5]; n_inf += k[6];
+    }
+    for (uint64_t i = 0; i < n_inf; ++i) {                 /* :187-198, in the order the sequential loop meets them */
+        const uint32_t c = s->inf_list[i];
+        citizen_t *z = &s->cit[c];
+        uint32_t b = z->cur;
+        if (s->inf_cnt[b] == 0) s->touched[s->n_touched++] = b;
+        s->inf_cnt[b]++;
+        z->inf_next = s->inf_head[b]; s->inf_head[b] = (int32_t)c;
+    }
+}
+
+int orc_set_threads(orc_sim *s, int threads)
+{
+#ifndef _OPENMP
+    threads = 1;
+#endif
+    if (threads < 1) threads = 1;
+    if (threads > 1 && !s->inf_list) {
+        s->inf_list = (uint32_t *)malloc(sizeof(uint32_t) * (s->n_cit ? s->n_cit : 1));
+        if (!s->inf_list) return -1;
+    }
+    free(s->thr_counts);
+    s->thr_counts = (uint64_t *)calloc(8u * (size_t)threads, sizeof(uint64_t));
+    if (!s->thr_counts) return -1;
+    s->threads = threads;
+    return threads;
+}
+
 int orc_step(orc_sim *s, orc_record *out)
 {
     const orc_params *P = &s->P;
@@ -349,6 +442,8 @@ int orc_step(orc_sim *s, orc_record *out)
 
     /* ---- generate_exposures, simulator.rs:155-260 ---- */
     s->n_riders = 0; s->n_touched = 0;
+    if (s->threads > 1) generate_exposures_threaded(s, &rec, hour, lockdown);
+    else
     for (uint32_t c = 0; c < s->n_cit; ++c) {
         citizen_t *z = &s->cit[c];
         citizen_execute_time_step(P, z, hour, lockdown);   /* :175-177 */

@@ -116,6 +116,10 @@ int      orc_run(orc_sim *s, uint32_t n, orc_record *out, int stop_when_done);
 void     orc_get_state(const orc_sim *s, uint8_t *status, uint16_t *timer,
                        uint8_t *at_work, uint8_t *bus, uint8_t *eligible);
 
+/* Runs the per-citizen pass of every later step on `threads` host threads (OpenMP; the reference uses rayon there,
+ * simulator.rs:167-260).  Results are identical to the single-threaded run.  Returns the thread count in force. */
+int      orc_set_threads(orc_sim *s, int threads);
+
 /* The add_exposure calls so far (statistics.rs:181-195), per citizen: time step (0 = none) and Output Area credited
  * (ORC_NO_ROOM: public transport). */
 void     orc_get_exposures(const orc_sim *s, uint32_t *step, uint32_t *area);

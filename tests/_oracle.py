@@ -46,6 +46,8 @@ def lib():
         L.orc_run.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
         L.orc_get_state.argtypes = [C.c_void_p, _u8p, C.POINTER(C.c_uint16), _u8p, _u8p, _u8p]
         L.orc_get_exposures.argtypes = [C.c_void_p, _u32p, _u32p]
+        L.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_threads.restype = C.c_int
         L.orc_default_params.argtypes = [C.POINTER(Params)]
         L.orc_binomial.restype = C.c_double
         L.orc_binomial.argtypes = [C.c_double, C.c_uint8]
@@ -112,6 +114,10 @@ class Oracle:
                             aw.ctypes.data_as(_u8p), bus.ctypes.data_as(_u8p), el.ctypes.data_as(_u8p))
         cur = np.where((aw == 1), self.pop.work_building, self.pop.home_building).astype(np.uint32)
         return {"status": st, "timer": tm, "current_building": cur, "on_bus": bus, "eligible": el}
+
+    def set_threads(self, n):
+        """Per-citizen pass of every later step on n host threads (same results); returns the count in force."""
+        return lib().orc_set_threads(self.h, int(n))
 
     def exposures(self):
         """(step, area) of every citizen's add_exposure call: step 0 = none, area 0xFFFFFFFF = public transport."""

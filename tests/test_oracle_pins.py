@@ -214,3 +214,25 @@ def test_reference_envelope_fixture_is_consistent():
     assert env["first_step_over"]["0.001"] < env["first_step_over"]["0.0022"] < env["first_step_over"]["0.0034"] \
         < env["first_step_over"]["0.005"]
     assert env["recovered_decreases"] is True                       # Q10: vaccination relabels R
+
+
+def test_threaded_per_citizen_pass_changes_nothing():
+    # orc_set_threads: the reference runs that pass under rayon (simulator.rs:167-260); records, states and the exposure
+    # record must not depend on the thread count
+    import numpy as np
+    from epidemicsimulator_amd import Population, _lib
+    pop = Population.synthetic("york", n_citizens=9000, n_areas=30, citizens_per_school=3000, n_seeds=15, p_public_transport=0.4)
+    ep = _lib.default_params(exposure_chance=0.004, vaccination_rate=40, vaccination_threshold=0.02, lockdown_threshold=0.03,
+                             mask_pt_threshold=0.005, mask_everywhere_threshold=0.01, seed=5)
+    runs = []
+    for threads in (1, 3, 8):
+        o = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
+        assert o.set_threads(threads) == threads
+        rec = o.run(300)
+        runs.append((rec, o.state(), o.exposures()))
+    for rec, st, ex in runs[1:]:
+        for f in rec.dtype.names:
+            assert (rec[f] == runs[0][0][f]).all(), f
+        assert all((st[k] == runs[0][1][k]).all() for k in st)
+        assert all((a == b).all() for a, b in zip(ex, runs[0][2]))
+    assert runs[0][0]["vaccinated"][-1] > 0 and runs[0][0]["exposures_bus"].sum() > 0
