@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--preset", default="uk64m", help="synthetic population preset (default: the benchmark workload)")
     ap.add_argument("--cpu-steps", type=int, default=48, help="time steps of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = all this process may use)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = what this process may use, at most 16)")
     ap.add_argument("--timing-stride", type=int, default=16, help="bracket the per-citizen kernels with HIP events every n-th step")
     ap.add_argument("--small-limit", type=int, default=None, help="override the persistent-kernel hand-over threshold (Infected citizens)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
@@ -192,7 +192,7 @@ def main():
                         compared += 1
                     out["golden_check"] = {"file": os.path.relpath(gpath, ROOT), "records_compared": compared, "match": True}
         if world == 1 and args.cpu_steps > 0:
-            n_thr = args.cpu_threads or len(os.sched_getaffinity(0))
+            n_thr = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))      # the GPU box gives one GPU's job 16 CPUs
             cb, orc_rec = cpu_baseline(pop, params, min(args.cpu_steps, steps), n_thr)
             out["cpu_baseline"] = cb
             for f in ("susceptible", "exposed", "infected", "recovered", "vaccinated"):

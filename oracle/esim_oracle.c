@@ -1,7 +1,8 @@
 /*
  * esim_oracle.c -- CPU ORACLE (test infrastructure; see esim_oracle.h header).
  *
- * Literal, single-threaded restatement of the reference's per-timestep loop.
+ * Literal restatement of the reference's per-timestep loop; single-threaded, except that orc_set_threads puts the
+ * per-citizen pass on several host threads with identical results.
  * Every function cites the reference file:line (relative to /root/reference)
  * it follows.  Data structures deliberately mirror the reference's shape
  * (array-of-struct citizens, per-building member lists, per-step rider lists,

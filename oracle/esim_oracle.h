@@ -5,7 +5,7 @@
  * `cpu_baseline` leg and __graft_entry__.smoke() may load it, and only as the
  * checker.  Nothing under epidemicsimulator_amd/ links, imports or calls it.
  *
- * It is a literal single-threaded restatement of the reference `sim` crate's
+ * It is a literal restatement (single-threaded unless orc_set_threads asks otherwise) of the reference `sim` crate's
  * `Simulator::step` (sim/src/simulator.rs:131-556 and the files it calls), with
  * one deliberate substitution: every `thread_rng()` draw is replaced by a
  * counter-based Philox4x32-10 draw (contract below), because the reference RNG
