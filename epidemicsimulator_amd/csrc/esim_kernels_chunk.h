@@ -296,7 +296,6 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
     const uint32_t per_wave = 4u * ((i1 - i0 + n_waves - 1u) / n_waves);
     if (wave == 0 && lane == 0) { ctrl->items_per_wave = per_wave; ctrl->n_items = per_wave * n_waves; }
     if ((unsigned long long)per_wave * n_waves > d.items_cap) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); return; }
-    for (uint32_t i = lane; i < per_wave; i += 64u) d.hitems[wave * per_wave + i] = ITEM_UNUSED;
     uint32_t next_id = wave * per_wave;
     const Decision q0 = lane < n ? d.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
     const Decision q1 = 64u + lane < n ? d.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
@@ -634,15 +633,17 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
     const uint32_t pt0 = PROF_NOW();
     uint32_t p_items = 0u, p_item_max = 0u;
-    // the items claimed by the wavefront of the same index in k_chunk_marks (same grid): ids [wave * per_wave, ...), handed
-    // out in order, so the first unused id ends the list.  (Striding over all ids instead would pile the items onto
-    // the few wavefronts whose index matches the low ids of every range.)
+    // the items claimed by the wavefront of the same index in k_chunk_marks (same grid): the first used_cnt[wave] ids of
+    // [wave * per_wave, ...).  (Striding over all ids instead would pile the items onto the few wavefronts whose index
+    // matches the low ids of every range.)
     const uint32_t per_wave = ld(&ctrl->items_per_wave);
-    const uint32_t v_lo = wave * per_wave, v_hi = min(v_lo + per_wave, n_items);
+    const uint32_t v_lo = wave * per_wave, v_cap = min(v_lo + per_wave, n_items);
+    const uint32_t used = d.used_cnt[wave];                                   // ids it handed out (needed only after the fetches below)
     // three items in flight: the record of the one after next (by id), the slot records of the next (by its slot), this one
     uint32_t id_cur = 0u, id_nxt = 0u, sl_cur = 0u;
-    if (v_lo < v_hi) id_cur = fetch_item(d, v_lo, lane);
-    if (v_lo + 1u < v_hi) id_nxt = fetch_item(d, v_lo + 1u, lane);
+    if (v_lo < v_cap) id_cur = fetch_item(d, v_lo, lane);                      // (fetched before `used` is known: in bounds either way)
+    if (v_lo + 1u < v_cap) id_nxt = fetch_item(d, v_lo + 1u, lane);
+    const uint32_t v_hi = min(v_lo + used, v_cap);
     // ... and the first look at the (route, bus step) pairs dealt to this wavefront (phase 2 below), so that they are here
     // when the items are done
     const uint32_t K = 2u * per_wave;                                          // pairs a stretch of the list can hold
