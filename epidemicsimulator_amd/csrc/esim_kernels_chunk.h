@@ -313,6 +313,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
     uint32_t c_n = 0u, w_n = 0u, k_n = 0u;
     if (i0 + wave < i1) { c_n = d.log[i0 + wave]; w_n = d.cit[c_n]; if (lane < 4u) k_n = key_src[c_n]; }
     uint32_t ps[5] = { 0u, 0u, 0u, 0u, 0u };                                   // diagnostics: time per stage
+    uint32_t ps_alu = 0u;
     const uint32_t pm_loop = PROF_NOW();
     for (uint32_t e = i0 + wave; e < i1; e += n_waves) {
         const uint32_t w = w_n, ksrc = k_n;
@@ -339,9 +340,11 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         if (lane == 3 && any_bus) key = (unsigned long long)d.n_bld + d.n_room + ksrc;
         uint32_t slot = 0u;
         bool pending = false, claimed = false;
+        const uint32_t pb2 = PROF_NOW();
         if (key != HKEY_EMPTY) claimed = item_probe(d, ctrl, key, slot, pending);
         const unsigned long long cm = __ballot(claimed);
         const uint32_t pc = PROF_NOW();
+        ps_alu += pb2 - pb;
         const uint32_t s_home = __shfl(slot, 0, 64), s_work = __shfl(slot, 1, 64), s_room = __shfl(slot, 2, 64);
         if (claimed) {
             const uint32_t v = next_id + (uint32_t)__popcll(cm & lt);
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
     const uint32_t pm1 = PROF_NOW();
     PROF_PUT(d, 8, pm0); PROF_PUT(d, 9, pm1); PROF_PUT(d, 10, p_entries);
     PROF_PUT(d, 11, ps[0]); PROF_PUT(d, 12, ps[1]); PROF_PUT(d, 13, ps[2]); PROF_PUT(d, 14, ps[3]); PROF_PUT(d, 15, ps[4]);
-    PROF_PUT(d, 6, pm_loop - pm0);
+    PROF_PUT(d, 6, pm_loop - pm0); PROF_PUT(d, 7, ps_alu); (void)ps_alu;
 }
 
 // A successful draw of citizen m in step s (bus: on public transport).

@@ -31,7 +31,7 @@ for target in (96, 192, 960, 1056, 1920, 2880, 3840, 4800, 4896, 4992):
     b = r[:, 10] > 0
     if b.any():
         print("        marks stages (waves with entries, median / max us): prologue %.1f/%.1f | word ready %.1f/%.1f | probe %.1f/%.1f | claim %.1f/%.1f | "
-              "wait %.1f/%.1f | counts+pairs %.1f/%.1f" % tuple(x for i in (6, 11, 12, 13, 14, 15) for x in (np.median(us(r[b, i])), us(r[b, i]).max())))
+              "wait %.1f/%.1f | counts+pairs %.1f/%.1f | (of probe: before the CAS %.1f/%.1f)" % tuple(x for i in (6, 11, 12, 13, 14, 15, 7) for x in (np.median(us(r[b, i])), us(r[b, i]).max())))
     big = np.zeros(16384 * 16, np.uint32)
     _lib.check(sim.lib.esim_prof_read(sim._ctx, big.ctypes.data_as(C.POINTER(C.c_uint32)), big.size, C.byref(khz)), sim._ctx)
     bk = big.reshape(16384, 16)[16383].astype(np.int64)
