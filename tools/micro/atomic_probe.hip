@@ -2,6 +2,7 @@
 // wavefronts issue them at once.  hipcc --offload-arch=gfx950 -O3 -o atomic_probe atomic_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <vector>
 #include <algorithm>
@@ -24,17 +25,20 @@ __global__ void probe(uint32_t *a, unsigned long long *b, uint32_t mask, int mod
     const uint32_t t1 = (uint32_t)wall_clock64();
     if (lane == 0) { out[2 * wave] = t1 - t0; out[2 * wave + 1] = acc; }
 }
-int main()
+int main(int argc, char **argv)
 {
-    const uint32_t n = 1u << 24;                    // 64 MB / 128 MB
+    const uint32_t n = 1u << (argc > 1 ? atoi(argv[1]) : 24);   // 2^24: 64 MB of u32 / 128 MB of u64 (the working set decides the TLB reach)
     uint32_t *a, *out; unsigned long long *b;
     hipMalloc(&a, n * 4); hipMalloc(&b, (size_t)n * 8); hipMalloc(&out, 2 * 16384 * 4);
     hipMemset(a, 0, n * 4); hipMemset(b, 0xFF, (size_t)n * 8);
     std::vector<uint32_t> h(2 * 16384);
     const char *names[] = { "load", "atomicAdd ret", "CAS64 ret", "atomicAdd noret + load" };
+    const bool quick = argc > 2;
+    printf("working set: %.0f MB (u32), %.0f MB (u64)\n", n * 4.0 / 1048576, n * 8.0 / 1048576);
     for (int mode = 0; mode < 4; ++mode)
         for (int lanes : { 1, 4, 64 })
             for (int blocks : { 1, 64, 1024, 2048 }) {
+                if (quick && !(lanes == 4 && blocks >= 1024)) continue;
                 const int reps = 8;
                 hipMemset(b, 0xFF, (size_t)n * 8);
                 hipLaunchKernelGGL(probe, dim3(blocks), dim3(256), 0, 0, a, b, n - 1, mode, lanes, reps, out);
