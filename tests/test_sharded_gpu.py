@@ -114,3 +114,23 @@ def test_syn3m5_two_generated_shards_match_oracle():
                params=dict(max_steps=800), steps=720, chunk=360)
     outs = launch(2, cfg, timeout=500)
     assert all("ok" in o for o in outs)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    # bench.py's N > 1 path end to end (weak scaling: every rank generates its own shard of a world twice the preset),
+    # two ranks sharing the test GPU and reducing over gloo -- the driver's N-GPU run uses the same code over nccl
+    port = free_port()
+    env = dict(os.environ, ESIM_BENCH_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "600", "--warmup", "24",
+           "--preset", "york", "--backend", "gloo", "--cpu-steps", "0"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 600 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["decoupled_steps"] == 600 and d["config"]["coupled_steps"] == 0
+    fr = d["final_record"]
+    assert fr["time_step"] == 600
+    assert fr["susceptible"] + fr["exposed"] + fr["infected"] + fr["recovered"] + fr["vaccinated"] == 2 * 197603
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
