@@ -75,6 +75,12 @@ class SynthSpec(C.Structure):
         ("n_seeds", C.c_uint32), ("seed", C.c_uint64), ("area_jitter", C.c_double),
         ("p_public_transport", C.c_double), ("p_mask_compliant", C.c_double),
         ("p_work_from_home", C.c_double), ("p_teaching", C.c_double),
+        ("household_buildings_median", C.c_double), ("household_buildings_sigma", C.c_double),
+        ("p_area_without_households", C.c_double),
+        ("workplace_buildings_median", C.c_double), ("workplace_buildings_sigma", C.c_double),
+        ("p_area_without_workplaces", C.c_double),
+        ("workplace_floor_median", C.c_double), ("workplace_floor_sigma", C.c_double),
+        ("teacher_candidate_schools", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 

@@ -27,10 +27,10 @@ _SUMMED = ("susceptible", "exposed", "infected", "recovered", "vaccinated", "exp
            "exposures_bus", "n_riders")
 
 
-def clean_cuts(pop, n_shards):
-    """Area boundaries for `n_shards` shards of a whole population: as even in citizens as possible among the
-    boundaries that no citizen commutes across (home area on one side, work building on the other); falls
-    back to the least-crossed boundary near the even split."""
+def clean_cuts(pop, n_shards, slack=0.1):
+    """Area boundaries for `n_shards` shards of a whole population: among the boundaries that keep every shard within
+    `slack` of an even share of the citizens, the one the fewest citizens commute across (home area on one side, work
+    building on the other)."""
     ah = pop.building_area[pop.home_building].astype(np.int64)
     aw = pop.building_area[pop.work_building].astype(np.int64)
     lo, hi = np.minimum(ah, aw), np.maximum(ah, aw)
@@ -48,8 +48,10 @@ def clean_cuts(pop, n_shards):
         if cand.size == 0:
             cuts.append(pop.n_areas)
             continue
-        cost = crossings[cand] * float(pop.n_citizens) + np.abs(cum[cand] - target)
-        cuts.append(int(cand[np.argmin(cost)]))
+        off = np.abs(cum[cand] - target)
+        near = cand[off <= max(off.min(), slack * pop.n_citizens / n_shards)]
+        cost = crossings[near] * float(pop.n_citizens) + np.abs(cum[near] - target)
+        cuts.append(int(near[np.argmin(cost)]))
     cuts.append(pop.n_areas)
     return np.maximum.accumulate(np.asarray(cuts, np.uint32))
 

@@ -256,17 +256,30 @@ int  esim_threshold_lut(const esim_params *p, uint64_t out[512]);
 typedef struct esim_synth_spec {
     uint32_t n_citizens, n_areas, citizens_per_school, n_seeds;
     uint64_t seed;
-    double   area_jitter;     /* per-area population = mean * (1 +- jitter) */
-    double   p_public_transport, p_mask_compliant, p_work_from_home, p_teaching;
+    double   area_jitter;     /* per-area census population = mean * (1 +- jitter) */
+    double   p_public_transport, p_mask_compliant;
+    double   p_work_from_home; /* extra share of adults without a workplace (0: only what the build leaves at home) */
+    double   p_teaching;       /* census group 9 "Elementary", mapped to Teaching */
+    /* the OSM side of SimulatorBuilder's inputs, per Output Area: log-normal counts round(median * exp(sigma z)) */
+    double   household_buildings_median, household_buildings_sigma;   /* dwellings; household size = pop / count + 1, output_area.rs:139 */
+    double   p_area_without_households;                               /* such areas get no citizens, simulator_builder.rs:226-235 */
+    double   workplace_buildings_median, workplace_buildings_sigma;   /* possible workplace buildings, simulator_builder.rs:717 */
+    double   p_area_without_workplaces;                               /* "No Workplace buildings exist", simulator_builder.rs:827-835 */
+    double   workplace_floor_median, workplace_floor_sigma;           /* floor area of one, m^2 (RawBuilding::size) */
+    uint32_t teacher_candidate_schools;                               /* MAX_ITEMS_RETURNED = 200, osm_data/src/quadtree.rs:544 */
+    uint32_t reserved;
 } esim_synth_spec;
 /* presets: "york", "yh_census", "syn3m5", "uk64m"  */
 int  esim_synth_preset(const char *name, esim_synth_spec *out);
-/* Allocates the arrays of *out (shared_* left empty); release with esim_synth_free. */
+/* Follows SimulatorBuilder::build (simulator_builder.rs:1162-1292) on synthetic census / OSM inputs: Output Areas are the
+ * cells of a near-square map in row-major order, households stand at points of their cell, students go to the closest
+ * school, teachers to the closest one lacking class teachers (else they are its secondary staff), workers to a
+ * workplace of their occupation inside their home area.  Allocates the arrays of *out (shared_* left empty); release
+ * with esim_synth_free. */
 int  esim_synth_create(const esim_synth_spec *spec, esim_population *out);
-/* The shard `shard` of `n_shards` of the same world, generated directly (without building the whole):
- * a run of whole school catchments, so it shares no building with other shards; citizen_id_base and
- * n_citizens_global are set, Philox counters stay global.  The shards of a spec concatenate to exactly
- * what esim_synth_create returns for it. */
+/* The shard `shard` of `n_shards` of the same world: the whole world is generated and cut (esim_shard_population) into
+ * bands of the map with about the same number of citizens each; citizen_id_base and n_citizens_global are set, Philox
+ * counters stay global.  Commuters to a school across a cut make that school (and its rooms) shared. */
 int  esim_synth_create_shard(const esim_synth_spec *spec, uint32_t shard, uint32_t n_shards, esim_population *out);
 void esim_synth_free(esim_population *pop);
 /* Cuts the shard of Output Areas [area_begin, area_end) out of a whole population:

@@ -136,3 +136,13 @@ class Oracle:
             self.close()
         except Exception:
             pass
+
+
+def state_digest(state):
+    """sha256 over the per-citizen state arrays (status u8, timer u16, current_building u32, on_bus u8, eligible u8),
+    in that order, little endian -- what the full-size goldens hold instead of 64 M rows."""
+    import hashlib
+    h = hashlib.sha256()
+    for name, dt in (("status", np.uint8), ("timer", "<u2"), ("current_building", "<u4"), ("on_bus", np.uint8), ("eligible", np.uint8)):
+        h.update(np.ascontiguousarray(state[name], dtype=dt).tobytes())
+    return h.hexdigest()

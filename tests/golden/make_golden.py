@@ -54,6 +54,14 @@ def reference_envelope():
            "first_vaccinated_record": int(stats[int(np.argmax(vac > 0))]["time_step"]),
            "recovered_decreases": bool((np.diff(rec) < 0).any()),
            "seed_infected_first_record": int(stats[0]["infected"])}
+    # the same run's exposures.json: exposures per Output Area (statistics.rs:119-136 writes one series per area that had any)
+    expo = json.load(open(os.path.join(os.path.dirname(path), "exposures.json")))["OutputArea"]
+    per_area = np.sort(np.array([sum(v) for v in expo.values()]))[::-1]
+    out["exposures_source"] = "statistics_results/v1.7.1/1946157112TYPE299/exposures.json"
+    out["exposures_total"] = int(per_area.sum())
+    out["areas_with_exposures"] = int(per_area.size)
+    out["exposures_share_top25_areas"] = float(per_area[:25].sum() / per_area.sum())
+    out["final_record"] = {k: int(stats[-1][k]) for k in ("time_step", "susceptible", "exposed", "infected", "recovered", "vaccinated")}
     with open(os.path.join(HERE, "reference_york_v171_envelope.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(out)

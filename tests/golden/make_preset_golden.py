@@ -1,6 +1,8 @@
-"""Golden records of the benchmark workloads at full size: the CPU oracle on a synthetic preset for 5000 steps (uk64m: about
-20 minutes and 6 GB on one core).  Writes tests/golden/oracle_<preset>_5000.json: every 50th record and the last.
-  python tests/golden/make_uk64m_golden.py [preset]"""
+"""Golden records of the benchmark workloads at full size: the CPU oracle on a synthetic preset for 5000 steps (uk64m: more
+than an hour and 6 GB).  Writes tests/golden/oracle_<preset>_5000.json: every record of the first 100 steps, every 50th
+record after that with the exposure totals of its block, and sha256 digests of the full per-citizen state after steps
+100 and 5000 (tests/_oracle.py: state_digest).
+  python tests/golden/make_preset_golden.py [preset] [oracle threads]"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,23 +10,32 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _oracle
 from epidemicsimulator_amd import Population, _lib
 
+FIELDS = ("time_step", "susceptible", "exposed", "infected", "recovered", "vaccinated", "exposures_building", "exposures_bus",
+          "lockdown", "vaccination_active", "mask_status", "n_riders", "vaccinated_now", "eligible_count")
 t0 = time.time()
 preset = sys.argv[1] if len(sys.argv) > 1 else "uk64m"
+threads = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 pop = Population.synthetic(preset)
 ep = _lib.default_params(max_steps=5000)
 orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
+if threads > 1:
+    orc.set_threads(threads)
 print("population %.0f s" % (time.time() - t0), flush=True)
-rows = []
+rows, first, digests = [], [], {}
 done = 0
 while done < 5000:
     r = orc.run(50)
     done += 50
-    rows.append({k: int(r[k][-1]) for k in ("time_step", "susceptible", "exposed", "infected", "recovered", "vaccinated",
-                                            "exposures_building", "exposures_bus", "lockdown", "mask_status")})
+    if done <= 100:
+        first += [{k: int(r[k][i]) for k in FIELDS} for i in range(50)]
+    rows.append({k: int(r[k][-1]) for k in FIELDS})
     rows[-1]["exposures_building_block"] = int(r["exposures_building"].sum())
     rows[-1]["exposures_bus_block"] = int(r["exposures_bus"].sum())
-    if done % 500 == 0:
+    if done in (100, 5000):
+        digests[str(done)] = _oracle.state_digest(orc.state())
+    if done % 250 == 0:
         print(done, rows[-1], "%.0f s" % (time.time() - t0), flush=True)
-json.dump({"preset": preset, "seed": int(ep.seed), "steps": 5000, "every": 50, "records": rows},
+json.dump({"preset": preset, "seed": int(ep.seed), "steps": 5000, "every": 50, "records": rows, "first_records": first,
+           "state_sha256": digests},
           open(os.path.join(ROOT, "tests", "golden", "oracle_%s_5000.json" % preset), "w"), indent=0)
 print("done %.0f s" % (time.time() - t0))

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported():
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.StepResult) == 64
     assert C.sizeof(_lib.Params) == 6 * 8 + 6 * 4 + 8 + 4 + 4
-    assert C.sizeof(_lib.SynthSpec) == 16 + 8 + 5 * 8
+    assert C.sizeof(_lib.SynthSpec) == 16 + 8 + 13 * 8 + 2 * 4
 
 
 def test_default_params_are_the_reference_constants():
@@ -43,16 +43,21 @@ def test_default_params_are_the_reference_constants():
 
 
 def test_synthetic_york_shape():
+    """The generator follows SimulatorBuilder::build on synthetic inputs; these are the shape facts of the reference's York
+    build (logs/pc_logs/v1.6/york.log:436-473) it must land near."""
     pop = Population.synthetic("york")
     assert pop.n_citizens == 197603 and pop.n_areas == 637
     bt = pop.building_type
-    assert (bt == _lib.SCHOOL).sum() == 25
+    assert (bt == _lib.SCHOOL).sum() == 25                            # york.log:446 "Generated 25 schools"
+    per_area = np.bincount(pop.building_area[pop.home_building], minlength=pop.n_areas)
+    assert 2 <= (per_area == 0).sum() <= 9                            # 5 areas without households, york.log:436
     students = (pop.occupation == 9).mean()
     assert 0.17 < students < 0.22                                     # Appendix B: 18-20 %
+    assert 0.09 < (pop.occupation == 8).mean() < 0.11                 # 19 948 "teachers" of 197 603
     assert 0.18 < (pop.flags & 1).mean() < 0.22                       # config.rs:36
     assert 0.78 < ((pop.flags >> 1) & 1).mean() < 0.82                # disease.rs:126
     wfh = (pop.home_building == pop.work_building).mean()
-    assert 0.09 < wfh < 0.14                                          # Appendix B: 10.8-12.5 %
+    assert 0.06 < wfh < 0.14                                          # Appendix B: 10.8-12.5 % (incl. 3 schools that were not built)
     # Q11: every non-school worker works in the home area
     non_school = bt[pop.work_building] != _lib.SCHOOL
     assert (pop.building_area[pop.work_building][non_school] == pop.building_area[pop.home_building][non_school]).all()
@@ -61,6 +66,25 @@ def test_synthetic_york_shape():
     assert (pop.room_building[pop.room[sch]] == pop.work_building[sch]).all()
     # citizens are ordered by home area, households are contiguous
     assert (np.diff(pop.home_building.astype(np.int64)) >= 0).all()
+    # households: pop / dwellings + 1 residents (output_area.rs:139) -- one size per area, the last one may be smaller
+    hh = np.bincount(pop.home_building, minlength=pop.n_buildings)[bt == _lib.HOUSEHOLD]
+    hh_area = pop.building_area[bt == _lib.HOUSEHOLD]
+    for a in (0, 100, 300, 636):
+        sizes = hh[hh_area == a]
+        if sizes.size:
+            assert (sizes[:-1] == sizes[0]).all() and sizes[-1] <= sizes[0]
+    assert 10 < (hh.astype(float) ** 2).sum() / hh.sum() < 20         # what a resident sees; calibrated, DESIGN.md 2
+    # workplaces never exceed max(max(floor, 2000) / density, 20) with the smallest density 10 (building.rs:236-250) unless the floor is huge
+    workers = np.bincount(pop.work_building[pop.work_building != pop.home_building], minlength=pop.n_buildings)[bt == _lib.WORKPLACE]
+    assert np.percentile(workers, 99) <= 200
+    # classes of at most ceil(26.6) students and one teacher; offices of 12 (building.rs:307-308)
+    room_size = np.bincount(pop.room[sch], minlength=pop.n_rooms)
+    assert room_size.max() <= 28
+    stud_rooms = np.unique(pop.room[sch & (pop.occupation == 9)])
+    class_teachers = sch & (pop.occupation == 8) & np.isin(pop.room, stud_rooms)
+    assert class_teachers.sum() == stud_rooms.size                    # every class got its teacher
+    # class teachers are the FIRST teachers in area order (simulator_builder.rs:489-527): they travel far, the others go to the closest school
+    assert pop.building_area[pop.home_building][class_teachers].max() < 100
     # deterministic
     again = Population.synthetic("york")
     assert (again.work_building == pop.work_building).all() and (again.seeds == pop.seeds).all()
@@ -86,39 +110,38 @@ def test_sharding_covers_the_population():
     assert sum(s.n_seeds for s in shards) == pop.n_seeds
 
 
-def test_generated_shards_concatenate_to_the_whole():
+def test_generated_shards_are_the_even_cut_of_the_whole():
     spec = dict(n_citizens=30000, n_areas=90, citizens_per_school=2500, n_seeds=25)
     whole = Population.synthetic("york", **spec)
     shards = [Population.synthetic_shard(i, 4, "york", **spec) for i in range(4)]
+    cut = [whole.shard(whole.even_cuts(4), i) for i in range(4)]
     assert [s.citizen_id_base for s in shards] == list(np.cumsum([0] + [s.n_citizens for s in shards[:-1]]))
     assert sum(s.n_citizens for s in shards) == whole.n_citizens
-    assert all(s.n_citizens_global == whole.n_citizens and s.n_shared_buildings == 0 for s in shards)
+    assert all(s.n_citizens_global == whole.n_citizens for s in shards)
     assert (np.concatenate([s.flags for s in shards]) == whole.flags).all()
     assert (np.concatenate([s.age for s in shards]) == whole.age).all()
-    b0, r0 = 0, 0
-    for s in shards:                                  # buildings and rooms are renumbered per shard, in order
-        lo = s.citizen_id_base
-        assert (s.home_building + b0 == whole.home_building[lo:lo + s.n_citizens]).all()
-        assert (s.work_building + b0 == whole.work_building[lo:lo + s.n_citizens]).all()
-        m = s.room != _lib.NO_ROOM
-        assert (s.room[m] + r0 == whole.room[lo:lo + s.n_citizens][m]).all()
-        assert (s.building_area == whole.building_area[b0:b0 + s.n_buildings]).all()
-        assert (s.building_type == whole.building_type[b0:b0 + s.n_buildings]).all()
-        b0 += s.n_buildings
-        r0 += s.n_rooms
-    assert b0 == whole.n_buildings and r0 == whole.n_rooms
+    for s, c in zip(shards, cut):
+        for name in ("home_building", "work_building", "room", "building_area", "building_type", "room_building", "seeds",
+                     "shared_building_local", "shared_room_local"):
+            assert (getattr(s, name) == getattr(c, name)).all(), name
+    # commuters to a school across a cut make it shared, with the same table length on every shard
+    assert shards[0].n_shared_buildings > 0 and len({s.n_shared_buildings for s in shards}) == 1
     seeds = sorted(int(x) + s.citizen_id_base for s in shards for x in s.seeds)
     assert seeds == sorted(whole.seeds.tolist())
 
 
-def test_clean_cuts_avoid_commuters():
+def test_clean_cuts_prefer_boundaries_few_commute_across():
     from epidemicsimulator_amd.distributed import clean_cuts
     pop = Population.synthetic("york", n_citizens=40000, n_areas=120, citizens_per_school=2500)
     cuts = clean_cuts(pop, 4)
     shards = [pop.shard(cuts, i) for i in range(4)]
-    assert all(s.n_shared_buildings == 0 and s.n_shared_rooms == 0 for s in shards)
     sizes = [s.n_citizens for s in shards]
     assert max(sizes) < 1.5 * min(sizes)
+    ah = pop.building_area[pop.home_building].astype(np.int64)
+    aw = pop.building_area[pop.work_building].astype(np.int64)
+    crossing = lambda b: int(((np.minimum(ah, aw) < b) & (np.maximum(ah, aw) >= b)).sum())
+    even = pop.even_cuts(4)
+    assert sum(crossing(int(b)) for b in cuts[1:-1]) <= sum(crossing(int(b)) for b in even[1:-1])
 
 
 def test_compute_fails_loudly_without_gpu(has_gpu):

@@ -205,15 +205,44 @@ def test_oracle_golden_trajectory_fixture():
         assert rec[k].tolist() == want, k
 
 
-def test_reference_envelope_fixture_is_consistent():
-    """Distributional envelope from the reference's recorded York run (v1.7.1): not bit-exact, only
-    the facts the reference's own output shows."""
+def test_oracle_meets_the_reference_recorded_york_run():
+    """THE pin between the oracle and something the reference produced.  The reference's one recorded run with the current
+    parameters (York, v1.7.1: 197 603 citizens, 5000 steps, 85 vaccinations per step) is a single OS-seeded sample, so the
+    comparison is distributional: the oracle runs the `york` preset under 8 (population seed, Philox seed) pairs with those
+    parameters, and every fact the fixture holds about the reference's records must lie inside the spread of the 8 runs
+    widened by WIDEN.  The facts about the records' timing and peaks were used to calibrate the one input of the synthetic
+    population that no log of the reference pins (dwellings OSM tags per Output Area, popgen.cpp); the facts from
+    exposures.json (total exposures of the run, Output Areas that saw any, their concentration) were not.
+    tests/golden/make_golden.py derives the fixture from the reference's output files; tools/envelope.py prints the runs."""
+    import _envelope
+    WIDEN = 1.25
     with open(os.path.join(GOLDEN, "reference_york_v171_envelope.json")) as f:
         env = json.load(f)
-    assert env["n_citizens"] == 197603
-    assert env["first_step_over"]["0.001"] < env["first_step_over"]["0.0022"] < env["first_step_over"]["0.0034"] \
-        < env["first_step_over"]["0.005"]
-    assert env["recovered_decreases"] is True                       # Q10: vaccination relabels R
+    assert env["n_citizens"] == 197603 and env["recovered_decreases"] is True       # Q10: vaccination relabels Recovered
+    runs = _envelope.ensemble(8, steps=5000, workers=min(4, os.cpu_count() or 1))
+
+    def inside(name, ref, values, widen=WIDEN):
+        got = [v for v in values if v is not None]
+        assert got, "%s: never happened in any run (reference: %s)" % (name, ref)
+        lo, hi = min(got) / widen, max(got) * widen
+        assert lo <= ref <= hi, "%s: reference %s outside the widened spread [%.4g, %.4g] of %s" % (name, ref, lo, hi, values)
+
+    for th, ref_step in env["first_step_over"].items():
+        inside("first step with more than %s infected" % th, ref_step, [r["first_step_over"][th] for r in runs])
+    for key in ("peak_infected", "peak_exposed", "first_vaccinated_record", "exposures_total", "areas_with_exposures"):
+        inside(key, env[key], [r[key] for r in runs])
+    inside("exposures_share_top25_areas", env["exposures_share_top25_areas"], [r["exposures_share_top25_areas"] for r in runs], widen=1.1)
+    # how fast the epidemic takes off once it is established (0.1 % -> 0.5 % infected) -- the fact that told the household
+    # sizes apart: 200 steps in the reference, 600-900 with households of 2..5 (round 1's generator)
+    inside("steps from 0.1 % to 0.5 % infected", env["first_step_over"]["0.005"] - env["first_step_over"]["0.001"],
+           [r["first_step_over"]["0.005"] - r["first_step_over"]["0.001"] for r in runs if r["first_step_over"]["0.005"]])
+    # a seed drawn in an area without citizens is lost (simulator_builder.rs:1125-1136), so 10 is the maximum
+    assert all(8 <= r["seed_infected_first_record"] <= env["seed_infected_first_record"] for r in runs)
+    assert sum(r["recovered_decreases"] for r in runs) >= 6
+    # and the spread itself must stay informative: the median run within a factor 1.5 of the reference
+    for key in ("peak_infected", "exposures_total"):
+        med = float(np.median([r[key] for r in runs]))
+        assert env[key] / 1.5 <= med <= env[key] * 1.5, (key, med, env[key])
 
 
 def test_threaded_per_citizen_pass_changes_nothing():

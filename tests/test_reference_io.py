@@ -83,10 +83,12 @@ def test_serde_shape_of_the_reference_types_is_accepted():
 
 def test_what_the_device_cannot_represent_is_refused():
     areas = population_to_reference_json(small_pop())
+    areas = [a for a in areas if len(a["citizens"]) > 1] + [a for a in areas if len(a["citizens"]) <= 1]
     areas[0]["citizens"][0]["start_working_hour"] = 7
     with pytest.raises(ReferenceFormatError, match="schedule is global"):
         population_from_reference_json(areas)
     areas = population_to_reference_json(small_pop())
+    areas = [a for a in areas if len(a["citizens"]) > 1] + [a for a in areas if len(a["citizens"]) <= 1]
     areas[1]["citizens"][0]["id"]["global_index"] = areas[1]["citizens"][1]["id"]["global_index"]
     with pytest.raises(ReferenceFormatError, match="repeated"):
         population_from_reference_json(areas)
