@@ -146,3 +146,55 @@ def state_digest(state):
     for name, dt in (("status", np.uint8), ("timer", "<u2"), ("current_building", "<u4"), ("on_bus", np.uint8), ("eligible", np.uint8)):
         h.update(np.ascontiguousarray(state[name], dtype=dt).tobytes())
     return h.hexdigest()
+
+
+# ---- the reference-shaped multithreaded CPU path (oracle/esim_refshape.cpp): same records as the oracle ----
+REFSHAPE_PATH = os.path.join(ROOT, "oracle", "libesim_refshape.so")
+_rsh = None
+
+
+def refshape_lib():
+    global _rsh
+    if _rsh is None:
+        lib()                                   # libesim_oracle.so first: the reference-shaped library links against it
+        L = C.CDLL(REFSHAPE_PATH)
+        L.rsh_create.restype = C.c_void_p
+        L.rsh_create.argtypes = [C.POINTER(Params), C.POINTER(Pop), C.c_int]
+        L.rsh_destroy.argtypes = [C.c_void_p]
+        L.rsh_run.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        _rsh = L
+    return _rsh
+
+
+class ReferenceShaped:
+    """Area-parallel array-of-structs run with the reference's locks and hash maps, on `threads` host threads."""
+
+    def __init__(self, pop, params=None, threads=1):
+        self.params = params or default_params()
+        self._keep = [np.ascontiguousarray(a) for a in (
+            pop.home_building.astype(np.uint32), pop.work_building.astype(np.uint32), pop.room.astype(np.uint32),
+            pop.flags.astype(np.uint8), pop.building_area.astype(np.uint32), pop.building_type.astype(np.uint8),
+            pop.room_building.astype(np.uint32), pop.seeds.astype(np.uint32))]
+        h, w, r, f, ba, bt, rb, sd = self._keep
+        s = Pop(pop.n_citizens, pop.n_buildings, pop.n_areas, pop.n_rooms, pop.n_seeds,
+                h.ctypes.data_as(_u32p), w.ctypes.data_as(_u32p), r.ctypes.data_as(_u32p), f.ctypes.data_as(_u8p),
+                ba.ctypes.data_as(_u32p), bt.ctypes.data_as(_u8p), rb.ctypes.data_as(_u32p), sd.ctypes.data_as(_u32p))
+        self.threads = int(threads)
+        self.h = refshape_lib().rsh_create(C.byref(self.params), C.byref(s), self.threads)
+
+    def run(self, n):
+        out = np.zeros(n, RECORD_DTYPE)
+        if refshape_lib().rsh_run(self.h, n, out.ctypes.data) < 0:
+            raise RuntimeError("reference-shaped path: S underflow")
+        return out
+
+    def close(self):
+        if self.h:
+            refshape_lib().rsh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
