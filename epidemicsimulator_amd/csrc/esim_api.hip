@@ -32,6 +32,7 @@ struct esim_ctx_impl {
     uint32_t last_chunk_pairs = 0;               // Infected during the chunk last looked at (picks the form of the chunk's book-keeping)
     uint32_t free_limit = 0, free_first = 0;     // open burst of decoupled chunks: last step it may reach, first step
     uint32_t host_t = 1;          // next time step to enqueue
+    uint64_t pop_hash = 0;        // of the uploaded population arrays: a checkpoint only goes back into the population it came from
     // device allocations
     std::vector<void *> allocs;
     // timing
@@ -47,6 +48,9 @@ struct esim_ctx_impl {
     hipEvent_t cev[2] = { nullptr, nullptr }; double chunk_ms = 0; uint64_t chunk_steps = 0, chunk_count = 0;
     uint32_t grid_chunk = 1024;
     bool pipeline = true;              // run chunks of steps as one kernel per step while no vaccination programme runs
+    bool vax_chunks = true;            // time-parallel chunks also under a vaccination programme (their vaccinations planned ahead, k_chunk_vax)
+    uint64_t vax_chunk_steps = 0, vax_chunk_cuts = 0;
+    bool elig_seen = false;            // the last control block read back had an eligible set (a vaccination programme runs)
     std::vector<hipEvent_t> fev; size_t fev_used = 0;                               // chunks of an open decoupled burst
     std::vector<hipEvent_t> pkev; size_t pkev_used = 0; uint64_t pipe_steps = 0;   // sampled k_pipe launches
     uint32_t small_max = 128;          // infected-slice length up to which the persistent single-workgroup kernel runs a step
@@ -244,6 +248,17 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     for (uint32_t i = 0; i < pop->n_shared_rooms; ++i)
         if (pop->shared_room_local[i] >= (int32_t)R) return fail(c, ESIM_EINVAL, "esim_upload_population: shared room out of range");
 
+    {
+        // FNV-1a over what the path reads of the population (checkpoints carry it, esim_checkpoint_restore compares it)
+        uint64_t h = 0xcbf29ce484222325ull;
+        auto mix = [&](const void *p, size_t nbytes) { const uint8_t *q = (const uint8_t *)p; for (size_t i = 0; i < nbytes; ++i) { h ^= q[i]; h *= 0x100000001b3ull; } };
+        mix(pop->home_building, sizeof(uint32_t) * (size_t)N); mix(pop->work_building, sizeof(uint32_t) * (size_t)N);
+        mix(pop->room, sizeof(uint32_t) * (size_t)N); mix(pop->flags, (size_t)N);
+        mix(pop->building_area, sizeof(uint32_t) * (size_t)B); mix(pop->building_type, (size_t)B);
+        if (R) mix(pop->room_building, sizeof(uint32_t) * (size_t)R);
+        if (pop->n_seeds) mix(pop->seeds, sizeof(uint32_t) * (size_t)pop->n_seeds);
+        c->pop_hash = h;
+    }
     // ---- public transport routes: riders sharing (home area, work area), simulator.rs:181-186.
     // Both travel directions group the same citizens, so one static list serves every bus step.
     std::vector<std::pair<uint64_t, uint32_t>> pairs;
@@ -374,6 +389,15 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if ((rc = dev_alloc(c, &d.touched_route[p], n_routes))) return rc;
         if ((rc = dev_alloc(c, &d.touched_route_big[p], n_routes))) return rc;
     }
+    if ((rc = dev_alloc(c, &d.vax_ev, (size_t)FREE_MAX * VACC_MAX_RATE))) return rc;
+    if ((rc = dev_alloc(c, &d.vax_cnt, FREE_MAX))) return rc;
+    if ((rc = dev_alloc(c, &d.vax_now, FREE_MAX))) return rc;
+    if ((rc = dev_alloc(c, &d.vax_delta, 4u * (FREE_MAX + 2u)))) return rc;
+    if ((rc = dev_alloc(c, &d.xf_adj, FREE_MAX + 2u))) return rc;
+    HIP_TRY(c, hipMemset(d.vax_cnt, 0, sizeof(uint32_t) * FREE_MAX));
+    HIP_TRY(c, hipMemset(d.vax_now, 0, sizeof(uint32_t) * FREE_MAX));
+    HIP_TRY(c, hipMemset(d.vax_delta, 0, sizeof(uint32_t) * 4u * (FREE_MAX + 2u)));
+    HIP_TRY(c, hipMemset(d.xf_adj, 0, sizeof(uint32_t) * (FREE_MAX + 2u)));
     if ((rc = dev_alloc(c, &d.hist, TE_SLOTS))) return rc;
     if ((rc = dev_alloc(c, &d.log, (size_t)N + 1))) return rc;
     if ((rc = dev_alloc(c, &d.log_off, TE_SLOTS + 1))) return rc;
@@ -462,6 +486,7 @@ extern "C" int esim_reset(esim_ctx *ctx)
     c->small_ms = 0; c->small_steps = 0;
     c->pkev_used = 0; c->pipe_steps = 0;
     c->chunk_ms = 0; c->chunk_steps = 0; c->chunk_count = 0;
+    c->vax_chunk_steps = 0; c->vax_chunk_cuts = 0; c->elig_seen = false;
     return ESIM_OK;
 }
 
@@ -629,6 +654,24 @@ void enqueue_parallel_chunk(esim_ctx_impl *c, int then_next, uint32_t limit_t)
     if (!small) hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d);
 }
 
+// One time-parallel chunk under a vaccination programme: census ahead, the plan of the chunk's vaccinations and what it does
+// to the Infected census, the decisions, then the pass itself in its wide form.  Every kernel takes the chunk from the
+// control block; a chunk that cannot run (no plan possible, a step that must run sequentially first) is a no-op.
+void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
+{
+    Dev &d = c->d;
+    hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+    hipLaunchKernelGGL(k_chunk_vax, dim3(FREE_MAX), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+    hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1);
+    hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, 0, 0, (uint32_t)c->xf_n, limit_t);
+    hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d);
+}
+
 // One pipelined chunk.  Precondition: k_future ran for the current step (and, when sharded, buffer F was
 // all-reduced).  k_decide finds how many of the next n_ahead steps can run before a vaccination programme
 // would start; those run as one k_pipe each and k_batch_finish writes their books.  *executed = steps run.
@@ -682,12 +725,47 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
     bool sequential_only = !c->pipeline || c->phase_timing;
     bool stalled = false, probing = false;
     uint32_t backoff = 0, sync_chunks_left = 0;
+    // a vaccination programme runs: chunks with their vaccinations planned, or sequential steps (short runs: sequential)
+    const bool vax_ok = c->time_parallel && c->vax_chunks && d.n_shards == 1u;
+    bool vax_regime = vax_ok && c->elig_seen;
+    if (c->elig_seen && (!vax_ok || n_steps < 8u)) sequential_only = true;
+    uint32_t vax_fail = 0;
     while (remaining > 0) {
         if (sequential_only) {
             uint32_t done = 0;
             if ((rc = run_sequential(c, remaining, allow_early_stop, &done))) return rc;
             total += done;
             break;
+        }
+        if (vax_regime) {
+            // bursts of planned chunks; whatever stops one (a cut: the step at ctrl->t must run sequentially; no plan possible;
+            // a chunk that does not fit the one-pass form) is answered with sequential steps, more of them when it keeps happening
+            const uint32_t first = c->host_t, limit_t = first + remaining - 1u;
+            const uint32_t bursts = std::min<uint32_t>((remaining + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n, vax_fail ? 1u : 8u);
+            const bool tk = c->kernel_timing;
+            if (tk) { if (!c->cev[0]) { (void)hipEventCreate(&c->cev[0]); (void)hipEventCreate(&c->cev[1]); } HIP_TRY(c, hipEventRecord(c->cev[0], c->stream)); }
+            for (uint32_t g = 0; g < bursts; ++g) enqueue_vax_chunk(c, limit_t);
+            if (tk) HIP_TRY(c, hipEventRecord(c->cev[1], c->stream));
+            Ctrl h;
+            HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipGetLastError());
+            if (h.error) return fail(c, -(int)h.error, "device-side error");
+            const uint32_t done = h.t - first;
+            c->last_chunk_pairs = h.chunk_pairs;
+            if (tk && done) { float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->cev[0], c->cev[1])); c->chunk_ms += ms; c->chunk_steps += done; c->chunk_count += (done + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n; }
+            c->vax_chunk_steps += done; c->vax_chunk_cuts = h.vax_cuts;
+            c->host_t = h.t; total += done; remaining -= done;
+            if (h.finished && allow_early_stop) break;
+            if (remaining == 0) break;
+            if (done >= std::min<uint32_t>(remaining + done, bursts * (uint32_t)c->xf_n)) { vax_fail = 0; continue; }
+            vax_fail = done ? 1u : std::min<uint32_t>(vax_fail + 1u, 8u);
+            uint32_t seq = 0;
+            const uint32_t want = std::min<uint32_t>(remaining, vax_fail <= 1u ? 1u : (vax_fail <= 3u ? 8u : (uint32_t)c->xf_n));
+            if ((rc = run_sequential(c, want, allow_early_stop, &seq))) return rc;
+            total += seq; remaining -= seq;
+            if (seq < want) break;                                       // the run ended
+            continue;
         }
         if (c->time_parallel && !stalled && sync_chunks_left == 0) {
             // Chunks are enqueued back to back without waiting for their k_decide: every kernel takes the chunk from the
@@ -726,12 +804,23 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
         c->host_t = before.t + done; total += done; remaining -= done;
         if (before.finished) break;
         if (done < n_ahead && remaining > 0) {
-            if (before.have_elig || before.vacc_active) { sequential_only = true; continue; }
+            if (before.have_elig || before.vacc_active) {
+                c->elig_seen = true;
+                if (vax_ok && remaining >= 8u) vax_regime = true; else sequential_only = true;
+                continue;
+            }
             // the next step starts the vaccination programme (or a limit was hit): one sequential step, then look again
             uint32_t one = 0;
             if ((rc = run_sequential(c, 1, allow_early_stop, &one))) return rc;
             total += one; remaining -= one;
             if (one == 0) break;
+            Ctrl h;
+            HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (h.have_elig) {                                            // that step started the programme
+                c->elig_seen = true;
+                if (vax_ok && remaining >= 8u) vax_regime = true; else sequential_only = true;
+            }
         }
         if (allow_early_stop && done > 0) {
             // a chunk may have ended the run (disease gone): k_batch_finish set `finished`
@@ -867,6 +956,7 @@ extern "C" int esim_set_pipeline(esim_ctx *ctx, int enable)
     if (!c) return ESIM_EINVAL;
     c->pipeline = enable != 0;            // 0: sequential steps only
     c->time_parallel = enable >= 2;       // 1: one kernel per step (k_pipe); 2: all steps of a chunk in one pass
+    c->vax_chunks = enable >= 3;          // 3 (default): ... also while a vaccination programme runs, its vaccinations planned per chunk
     return ESIM_OK;
 }
 
@@ -1055,9 +1145,10 @@ struct CkptHeader {
     uint32_t magic, version, n, n_global, id_base, max_steps, host_t, log_len;
     uint32_t exposed_time, infected_time, vaccination_rate, bus_capacity, start_hour, end_hour, ctrl_bytes, reserved;
     uint64_t seed;
+    uint64_t pop_hash;
     double thresholds[6];
 };
-const uint32_t CKPT_MAGIC = 0x4D495345u /* "ESIM" */, CKPT_VERSION = 1u;
+const uint32_t CKPT_MAGIC = 0x4D495345u /* "ESIM" */, CKPT_VERSION = 2u;
 
 void ckpt_header(const esim_ctx_impl *c, const Ctrl &h, CkptHeader *o)
 {
@@ -1066,7 +1157,7 @@ void ckpt_header(const esim_ctx_impl *c, const Ctrl &h, CkptHeader *o)
     o->max_steps = c->P.max_steps; o->host_t = c->host_t; o->log_len = h.log_len;
     o->exposed_time = c->P.exposed_time; o->infected_time = c->P.infected_time; o->vaccination_rate = c->P.vaccination_rate;
     o->bus_capacity = c->P.bus_capacity; o->start_hour = c->P.start_hour; o->end_hour = c->P.end_hour; o->ctrl_bytes = (uint32_t)sizeof(Ctrl);
-    o->seed = c->P.seed;
+    o->seed = c->P.seed; o->pop_hash = c->pop_hash;
     const double th[6] = { c->P.exposure_chance, c->P.mask_effectiveness, c->P.lockdown_threshold, c->P.vaccination_threshold,
                            c->P.mask_pt_threshold, c->P.mask_everywhere_threshold };
     std::memcpy(o->thresholds, th, sizeof th);
@@ -1134,7 +1225,7 @@ extern "C" int esim_checkpoint_restore(esim_ctx *ctx, const void *buf, size_t by
     if (k.magic != CKPT_MAGIC || k.version != CKPT_VERSION || k.ctrl_bytes != sizeof(Ctrl)) return fail(c, ESIM_EINVAL, "esim_checkpoint_restore: not a checkpoint of this library version");
     if (k.n != mine.n || k.n_global != mine.n_global || k.id_base != mine.id_base || k.seed != mine.seed || k.exposed_time != mine.exposed_time ||
         k.infected_time != mine.infected_time || k.vaccination_rate != mine.vaccination_rate || k.bus_capacity != mine.bus_capacity ||
-        k.start_hour != mine.start_hour || k.end_hour != mine.end_hour || std::memcmp(k.thresholds, mine.thresholds, sizeof k.thresholds) != 0)
+        k.start_hour != mine.start_hour || k.end_hour != mine.end_hour || k.pop_hash != mine.pop_hash || std::memcmp(k.thresholds, mine.thresholds, sizeof k.thresholds) != 0)
         return fail(c, ESIM_EINVAL, "esim_checkpoint_restore: the checkpoint was taken with another population, shard or parameter set");
     if (k.host_t == 0 || k.host_t - 1u > c->P.max_steps || k.log_len > k.n) return fail(c, ESIM_EINVAL, "esim_checkpoint_restore: steps beyond this context's max_steps");
     if (bytes < ckpt_bytes(k)) return fail(c, ESIM_EINVAL, "esim_checkpoint_restore: truncated checkpoint");
@@ -1144,6 +1235,13 @@ extern "C" int esim_checkpoint_restore(esim_ctx *ctx, const void *buf, size_t by
     const uint8_t *p = (const uint8_t *)buf + sizeof k;
     Ctrl h;
     std::memcpy(&h, p, sizeof h); p += sizeof h;
+    // the control block goes to the device as it is: it must be the one of a context at rest at that step
+    if (h.t != k.host_t || h.log_len != k.log_len || h.error != 0u || h.steps_done + 1u != k.host_t || h.n_susceptible > k.n || h.n_vaccinated > k.n)
+        return fail(c, ESIM_EINVAL, "esim_checkpoint_restore: the control block does not match the checkpoint's header (corrupt file)");
+    h.chunk_ok = 0; h.chunk_parallel = 0; h.chunk_done = 0; h.n_items = 0; h.n_newexp = 0; h.n_units = 0; h.unit_next = 0;
+    h.n_route_pairs = 0; h.n_route_pairs_big = 0; h.prev_n_items = 0; h.prev_per_wave = 0; h.items_per_wave = 0; h.small_done = 0;
+    h.free_base = 0; h.n_riders = 0;
+    for (int z = 0; z < 5; ++z) h.counts[z] = 0;
     // marks of the last step are only ever cleared, never read, by the step after it: start without them
     for (uint32_t z = 0; z < MARK_SLOTS; ++z) { h.n_touched_bld[z] = 0; h.n_touched_room[z] = 0; h.n_touched_route[z] = 0; h.n_touched_route_big[z] = 0; }
     auto push = [&](void *dst, size_t nb) -> int { if (nb) HIP_TRY(c, hipMemcpy(dst, p, nb, hipMemcpyHostToDevice)); p += nb; return ESIM_OK; };
@@ -1156,6 +1254,7 @@ extern "C" int esim_checkpoint_restore(esim_ctx *ctx, const void *buf, size_t by
     HIP_TRY(c, hipMemcpy(d.ctrl, &h, sizeof h, hipMemcpyHostToDevice));
     c->host_t = k.host_t;
     c->last_chunk_pairs = h.chunk_pairs;
+    c->elig_seen = h.have_elig != 0u;
     return ESIM_OK;
 }
 

@@ -8,6 +8,9 @@
 //                   the E/I timers of disease.rs:47-71 never have to be written back.
 // bit  18      bus_exposed : the exposure happened on public transport (the citizen leaves
 //                   citizens_eligible_for_vaccine, simulator.rs:447-449)
+// bits 17..11  vax : only inside a time-parallel chunk that runs under a vaccination programme: 127 - j when the citizen
+//                   is set Vaccinated at the END of step j of the chunk (simulator.rs:524-553), 0 = not in this chunk.  The
+//                   earliest such step wins by atomicMax; k_chunk_scatter turns it into te = TE_VACCINATED and clears it.
 // bits 7..0    static flags (below)
 // te sits in the most significant bits and Susceptible is the largest te, so "exposed at the earliest step
 // at which any draw succeeds; a building beats a bus within a step" is one atomicMin on this word.
@@ -17,6 +20,13 @@
 #define CW_TE_SHIFT    19u
 #define CW_BUS_EXPOSED (1u << 18)
 #define CW_FLAGS       0xFFu
+#define CW_VAX_SHIFT   11u
+#define CW_VAX_MASK    (0x7Fu << CW_VAX_SHIFT)
+#define CW_KEEP        (CW_FLAGS | CW_VAX_MASK)            // what an exposure inside a chunk leaves as it is
+#define CW_VAX_NONE    0xFFFFFFFFu
+// step of the chunk at whose end the citizen becomes Vaccinated (CW_VAX_NONE: not in this chunk)
+#define CW_VAX_REL(w)  ((((w) >> CW_VAX_SHIFT) & 0x7Fu) ? 127u - (((w) >> CW_VAX_SHIFT) & 0x7Fu) : CW_VAX_NONE)
+#define CW_VAX_FIELD(j) ((127u - (j)) << CW_VAX_SHIFT)
 #define CW_TE(w)       ((w) >> CW_TE_SHIFT)
 #define CW_MAKE(te, rest) (((te) << CW_TE_SHIFT) | (rest))
 #define TE_SUSCEPTIBLE 0x1FFFu
@@ -78,6 +88,13 @@ struct Ctrl {
     uint32_t n_route_pairs_big; // ... routes of more riders
     uint32_t chunk_done;        // the books of the last time-parallel chunk were written (k_chunk_books)
     uint32_t prev_t0, prev_n_items, prev_per_wave; // that chunk, for k_chunk_scatter
+    // time-parallel chunks under a vaccination programme (k_chunk_vax)
+    uint32_t vax_chunk;         // 1: the chunk in preparation has its vaccinations planned (events in Dev::vax_ev, fields in the words)
+    uint32_t chunk_cut;         // first step of the chunk (relative) that must NOT be committed: a citizen exposed on a bus there had been
+                                // planned for vaccination at or after it (it left the eligible set, simulator.rs:447-449) -- FREE_MAX + 1: none
+    uint32_t need_seq;          // the step at ctrl->t must run in the sequential form (set with a cut, cleared by k_finish)
+    uint32_t prev_n, prev_n_eff, prev_vax; // the chunk k_chunk_scatter is finishing: its length, the steps committed, whether it was planned
+    uint32_t vax_cuts;          // diagnostics: chunks that were cut short
 };
 
 // A deferred unit of a long member list: UNIT_PAIRS (member, marked step) pairs from pair p_lo on.  code = kind << 30 | p_lo
@@ -139,6 +156,13 @@ struct Dev {
     uint32_t *hot;              // [HOT_COUNT * HOT_STRIDE] the counters of the lists above
     uint32_t *cursor;           // [FREE_MAX] per-step write cursors into the log
     uint32_t max_route;         // riders of the largest route
+    // vaccination inside time-parallel chunks
+    uint32_t *vax_ev;           // [FREE_MAX][VACC_MAX_RATE] citizens chosen in each step of the chunk, in candidate order
+    uint32_t *vax_cnt;          // [FREE_MAX] how many (this shard's)
+    uint32_t *vax_now;          // [FREE_MAX] vaccinated_now of the step's record (all shards)
+    uint32_t *vax_delta;        // [4][FREE_MAX + 2] difference arrays over the chunk's steps: Susceptible, Exposed, Infected, Vaccinated
+                                // census changes caused by the chunk's vaccinations (two's complement)
+    uint32_t *xf_adj;           // [FREE_MAX + 2] difference array: Infected census ahead minus those vaccinated before
     uint32_t *hist;             // [TE_SLOTS] citizens per exposure time (census without a pass over citizens)
     uint32_t *log;              // exposure log: citizen ids in order of exposure step
     uint32_t *log_off;          // [TE_SLOTS + 1] first log entry whose te >= k

@@ -85,7 +85,23 @@ __device__ __forceinline__ void decide_body(const Dev &d, uint32_t max_ahead, ui
     const uint32_t t0 = ld(&ctrl->t);
     const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
     const uint32_t lim_in = n_ahead < FREE_MAX ? n_ahead : FREE_MAX;
-    const bool ok = !ld(&ctrl->have_elig) && !ld(&ctrl->vacc_active) && !ld(&ctrl->finished) && !ld(&ctrl->error) && ld(&ctrl->free_base) == t0;
+    // under a vaccination programme only a chunk whose vaccinations are planned may run (k_chunk_vax); the Infected census ahead
+    // then loses those the plan vaccinates before (prefix sums of xf_adj)
+    const bool vax = ld(&ctrl->have_elig) != 0u;
+    const bool ok = (vax ? (ld(&ctrl->vax_chunk) != 0u) : !ld(&ctrl->vacc_active)) && !ld(&ctrl->need_seq) && !ld(&ctrl->finished) && !ld(&ctrl->error) && ld(&ctrl->free_base) == t0;
+    uint32_t adj[2] = { 0u, 0u };
+    if (vax && ok) {
+        uint32_t carry = 0u;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t jj = 64u * r + lane;
+            uint32_t x = jj < FREE_MAX ? ld(&d.xf_adj[jj]) : 0u;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= (uint32_t)o) x += y; }
+            adj[r] = x + carry;
+            carry += __shfl(x, 63, 64);
+        }
+    }
     const uint32_t lock_init = ld(&ctrl->lockdown), mask_init = ld(&ctrl->mask), work_init = ld(&ctrl->at_work), bus_init = ld(&ctrl->bus_dir);
     unsigned long long m_vacc[2], m_lock[2];
     uint32_t f_mask[2];                                   // transition function of the lane's step in each round
@@ -94,7 +110,7 @@ __device__ __forceinline__ void decide_body(const Dev &d, uint32_t max_ahead, ui
     for (int r = 0; r < 2; ++r) {
         const uint32_t j = 64u * r + lane;
         in[r] = j < lim_in && t0 + j <= d.max_steps;
-        const double x = in[r] ? (double)ld(&d.xf[j]) / (double)d.n_global : 0.0;   // infected_percentage, statistics.rs:252
+        const double x = in[r] ? (double)(ld(&d.xf[j]) + adj[r]) / (double)d.n_global : 0.0;   // infected_percentage, statistics.rs:252
         m_vacc[r] = __ballot(in[r] && d.thr_vacc < x);
         m_lock[r] = __ballot(in[r] && d.thr_lockdown < x);
         const uint32_t from_none = (in[r] && d.thr_mask_pt < x) ? 1u : 0u;
@@ -108,7 +124,7 @@ __device__ __forceinline__ void decide_body(const Dev &d, uint32_t max_ahead, ui
         const unsigned long long valid0 = __ballot(in[0]), valid1 = __ballot(in[1]);
         const uint32_t n_valid = (uint32_t)(__popcll(valid0) + __popcll(valid1));
         const uint32_t first_v = m_vacc[0] ? (uint32_t)__ffsll((long long)m_vacc[0]) - 1u : (m_vacc[1] ? 64u + (uint32_t)__ffsll((long long)m_vacc[1]) - 1u : n_valid);
-        n_ok = first_v < n_valid ? first_v : n_valid;
+        n_ok = (!vax && first_v < n_valid) ? first_v : n_valid;             // (a programme that runs cannot start again)
     }
     // exclusive scan of the mask transition functions (identity = 0b100100)
     uint32_t pre[2];
@@ -206,6 +222,117 @@ __global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32
     decide_body(d, max_ahead, limit_t, allow_parallel);
 }
 
+// ------------------------------------------------------------------ vaccination inside a chunk
+// While a vaccination programme runs (simulator.rs:524-553) every step sets `vaccination_rate` citizens Vaccinated: the
+// first k distinct members of citizens_eligible_for_vaccine in the candidate sequence of that step (RNG contract,
+// DESIGN.md 2).  Candidates are pure functions of (i, step), and the eligible set only ever loses citizens that are exposed
+// on public transport (simulator.rs:447-449, Q10) -- so who is vaccinated when is known for a whole chunk ahead, up to those
+// few removals.  k_chunk_vax plans the chunk: workgroup j takes step t0 + j, walks its candidate sequence exactly as
+// k_finish does, notes the chosen citizens (Dev::vax_ev) and leaves "Vaccinated at the end of step j" in their words
+// (earliest step wins, atomicMax on the vax field).  Everything downstream reads the field: an Infected citizen stops
+// marking after that step (k_chunk_marks), a Susceptible one takes no draw after it (member_pairs), the census moves
+// (k_chunk_vax_adj for the Infected counts the decisions need, k_chunk_count for the records).  The plan is speculative in
+// one respect only: a citizen it chose for step j may be exposed on a bus in a step s <= j of this very chunk, which removes
+// it from the set before its turn.  k_chunk_count finds the earliest such step s* (Ctrl::chunk_cut); the chunk is then
+// committed up to s* - 1, step s* runs in the sequential form (which removes the citizen properly), and chunks resume.
+__global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead, uint32_t limit_t)
+{
+    __shared__ FinishShared sm;
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t j = blockIdx.x;
+    const uint32_t t0 = ctrl->t;
+    const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
+    // (every workgroup takes the same decision from the same words; nothing here writes them)
+    const bool plan = ctrl->have_elig && !ctrl->finished && !ctrl->error && !ctrl->need_seq && d.n_shards == 1u &&
+                      ctrl->elig_count > d.vaccination_rate + d.n_pt;      // the set cannot shrink to the "whole set" case inside the chunk
+    if (tid == 0) {
+        d.xf_adj[j] = 0u;
+        for (uint32_t q = 0; q < 4u; ++q) d.vax_delta[q * (FREE_MAX + 2u) + j] = 0u;
+        d.vax_cnt[j] = 0u; d.vax_now[j] = 0u;
+        if (j == 0) {
+            ctrl->vax_chunk = plan ? 1u : 0u;
+            ctrl->chunk_cut = FREE_MAX + 1u;
+            for (uint32_t z = FREE_MAX; z < FREE_MAX + 2u; ++z) { d.xf_adj[z] = 0u; for (uint32_t q = 0; q < 4u; ++q) d.vax_delta[q * (FREE_MAX + 2u) + z] = 0u; }
+        }
+    }
+    if (!plan || j >= n_ahead) return;
+    const uint32_t t = t0 + j, k = d.vaccination_rate, tstep = ctrl->trigger_step;
+    for (uint32_t i = tid; i < VACC_TABLE; i += FIN_TPB) { sm.tab_key[i] = 0xFFFFFFFFu; sm.tab_idx[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    uint32_t already = 0;
+    for (uint32_t base = 0; already < k; base += VACC_BATCH) {
+        uint32_t cj[4], slot[4], cw[4]; bool live[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t i = base + tid * 4u + q;
+            cj[q] = vacc_candidate(d, i, t);
+            cw[q] = d.cit[cj[q]];
+            live[q] = eligible(cw[q], tstep);
+            slot[q] = 0;
+            if (live[q]) {
+                uint32_t sl = (cj[q] * 2654435761u) >> 18;        // 14 bits
+                for (;;) {
+                    const uint32_t old = atomicCAS(&sm.tab_key[sl], 0xFFFFFFFFu, cj[q]);
+                    if (old == 0xFFFFFFFFu || old == cj[q]) break;
+                    sl = (sl + 1u) & (VACC_TABLE - 1u);
+                }
+                atomicMin(&sm.tab_idx[sl], i);
+                slot[q] = sl;
+            }
+        }
+        __syncthreads();
+        bool first[4]; uint32_t mine = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { first[q] = live[q] && sm.tab_idx[slot[q]] == base + tid * 4u + q; mine += first[q]; }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= (uint32_t)o) incl += v; }
+        if (lane == 63) sm.wsum[wv] = incl;
+        __syncthreads();
+        if (tid == 0) { uint32_t a = 0; for (uint32_t w = 0; w < FIN_TPB / 64; ++w) { const uint32_t v = sm.wsum[w]; sm.wsum[w] = a; a += v; } sm.s_total = a; }
+        __syncthreads();
+        uint32_t pos = already + sm.wsum[wv] + incl - mine;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (first[q]) {
+                if (pos < k) {
+                    d.vax_ev[(size_t)j * VACC_MAX_RATE + pos] = cj[q];
+                    // unconditional (simulator.rs:551) -- but a citizen that is Vaccinated already stays what it is
+                    if (CW_TE(cw[q]) != TE_VACCINATED) atomicMax(&d.cit[cj[q]], (cw[q] & ~CW_VAX_MASK) | CW_VAX_FIELD(j));
+                }
+                pos++;
+            }
+        }
+        const uint32_t got = sm.s_total;
+        __syncthreads();
+        already += got < k - already ? got : k - already;
+        if (base >= (1u << 26) && already < k) { if (tid == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); break; }   // every wave must reach an exit
+    }
+    if (tid == 0) { d.vax_cnt[j] = already; d.vax_now[j] = already; }
+}
+
+// The Infected census ahead (buffer F) counts everybody whose exposure step makes it Infected; those the plan vaccinates
+// before leave it.  One thread per planned citizen: if its own step is the one that won, and the citizen is Infected in some
+// later step of the chunk, that stretch goes into the difference array xf_adj (k_decide adds its prefix sums to F).
+__global__ __launch_bounds__(TPB) void k_chunk_vax_adj(Dev d, uint32_t max_ahead, uint32_t limit_t)
+{
+    const Ctrl *ctrl = d.ctrl;
+    if (!ctrl->vax_chunk) return;
+    const uint32_t t0 = ctrl->t;
+    const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
+    const uint32_t j = blockIdx.x;
+    if (j >= n_ahead) return;
+    const uint32_t cnt = d.vax_cnt[j];
+    for (uint32_t i = threadIdx.x; i < cnt; i += TPB) {
+        const uint32_t w = d.cit[d.vax_ev[(size_t)j * VACC_MAX_RATE + i]], te = CW_TE(w);
+        if (CW_VAX_REL(w) != j || te >= TE_RECOVERED) continue;                // not the winning step / never exposed
+        const int a = (int)te - (int)TE_BIAS + (int)d.exposed_time + 1 - (int)t0;   // Infected in steps [a, a + infected_time] of the chunk
+        const int lo = a > (int)j + 1 ? a : (int)j + 1, hi = min(a + (int)d.infected_time, (int)n_ahead - 1);
+        if (lo <= hi) { atomicSub(&d.xf_adj[lo], 1u); atomicAdd(&d.xf_adj[hi + 1], 1u); }
+    }
+}
+
 // Marks of the first step of a chunk (the later ones are made by the k_pipe of the step before).
 // ------------------------------------------------------------------------- time-parallel chunk
 // Inside a chunk nothing a draw depends on changes: who is Infected and where (known ahead), the mask
@@ -262,11 +389,20 @@ __device__ __forceinline__ uint32_t iv_present(uint32_t iv, uint32_t j, const De
     return ((iv & IV_AS_WORK) != 0u) == at_work ? 1u : 0u;
 }
 
-// Where an Infected citizen stands in step s of the chunk (simulator.rs:181-198): bit 0 in the home building,
-// bit 1 in the work building, bit 2 on the bus.  0 when not Infected in that step.
-__device__ __forceinline__ uint32_t where_in_step(const Dev &d, uint32_t w, uint32_t s, const Decision &q)
+// DiseaseStatus of a citizen in step t0 + j of a chunk: a vaccination planned for the end of step f of the chunk
+// (k_chunk_vax) makes it Vaccinated from step f + 1 on, whatever it was (simulator.rs:551).
+__device__ __forceinline__ uint32_t status_in_chunk(const Dev &d, uint32_t w, uint32_t t0, uint32_t j)
 {
-    if (status_of(CW_TE(w), s, d.exposed_time, d.infected_time) != ESIM_INFECTED) return 0u;
+    const uint32_t f = CW_VAX_REL(w);
+    if (f != CW_VAX_NONE && j > f) return ESIM_VACCINATED;
+    return status_of(CW_TE(w), t0 + j, d.exposed_time, d.infected_time);
+}
+
+// Where an Infected citizen stands in step t0 + j of the chunk (simulator.rs:181-198): bit 0 in the home building,
+// bit 1 in the work building, bit 2 on the bus.  0 when not Infected in that step.
+__device__ __forceinline__ uint32_t where_in_step(const Dev &d, uint32_t w, uint32_t t0, uint32_t j, const Decision &q)
+{
+    if (status_in_chunk(d, w, t0, j) != ESIM_INFECTED) return 0u;
     if (q.bus_dir && (w & FL_USES_PT)) return 4u;
     return (q.at_work && (w & FL_HAS_WORK)) ? 2u : 1u;
 }
@@ -319,8 +455,8 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         const uint32_t w = w_n, ksrc = k_n;
         const uint32_t pa = PROF_NOW();
         if (e + n_waves < i1) { c_n = d.log[e + n_waves]; w_n = d.cit[c_n]; if (lane < 4u) k_n = key_src[c_n]; }
-        const uint32_t p0 = lane < n ? where_in_step(d, w, t0 + lane, q0) : 0u;
-        const uint32_t p1 = 64u + lane < n ? where_in_step(d, w, t0 + 64u + lane, q1) : 0u;
+        const uint32_t p0 = lane < n ? where_in_step(d, w, t0, lane, q0) : 0u;
+        const uint32_t p1 = 64u + lane < n ? where_in_step(d, w, t0, 64u + lane, q1) : 0u;
         const bool any_home = __any((p0 | p1) & 1u), any_work = __any((p0 | p1) & 2u), any_bus = __any((p0 | p1) & 4u);
         const bool school = w & FL_WORK_SCHOOL;
         if (!any_home && !any_work && !any_bus) continue;
@@ -330,7 +466,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         // them follows from the record's flags and the step's schedule (iv_present)
         const int a_abs = (int)CW_TE(w) - (int)TE_BIAS + (int)d.exposed_time + 1;
         const uint32_t iv_a = a_abs > (int)t0 ? (uint32_t)(a_abs - (int)t0) : 0u;
-        const uint32_t iv_b = min((uint32_t)(a_abs + (int)d.infected_time - (int)t0), n - 1u);
+        const uint32_t iv_b = min(min((uint32_t)(a_abs + (int)d.infected_time - (int)t0), n - 1u), CW_VAX_REL(w));   // (CW_VAX_NONE is the largest value)
         const uint32_t iv = IV_VALID | iv_a | (iv_b << 7) | ((w & FL_USES_PT) ? IV_PT : 0u) | ((w & FL_HAS_WORK) ? IV_HW : 0u) |
                             ((lane == 1u || lane == 2u) ? IV_AS_WORK : 0u);
         unsigned long long key = HKEY_EMPTY;
@@ -437,7 +573,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
 // A successful draw of citizen m in step s (bus: on public transport).
 __device__ __forceinline__ void expose_min(const Dev &d, Ctrl *ctrl, uint32_t m, uint32_t w, uint32_t s, uint32_t bus)
 {
-    const uint32_t cand = CW_MAKE(s + TE_BIAS, bus | (w & CW_FLAGS));
+    const uint32_t cand = CW_MAKE(s + TE_BIAS, bus | (w & CW_KEEP));
     const uint32_t prev = atomicMin(&d.cit[m], cand);
     if (cand < prev && CW_TE(prev) == TE_SUSCEPTIBLE) {                       // first exposure in this chunk
         const uint32_t r = m & (SUBQ - 1u);
@@ -488,7 +624,8 @@ __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const Chu
             if (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) continue;
             // Susceptible when this list is walked in step s: never exposed, or so far only exposed by something that
             // comes later (a later step, or a bus of this step) -- that exposure may be undercut
-            if (w <= CW_MAKE(s + TE_BIAS, w & CW_FLAGS)) continue;
+            if (w <= CW_MAKE(s + TE_BIAS, w & CW_KEEP)) continue;
+            if (j > CW_VAX_REL(w)) continue;                                                // Vaccinated by then (k_chunk_vax)
             const uint32_t at_work = sm.dec[j].at_work, mask = sm.dec[j].mask;
             const bool same = w & FL_SAME_AREA;
             if (kind == 0u) { if (at_work && (w & FL_HAS_WORK) && !same) continue; }       // simulator.rs:324
@@ -738,7 +875,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
         if (lane < sz) {
             c = d.route_riders[off + lane];
             w = d.cit[c];
-            inf = status_of(CW_TE(w), s, d.exposed_time, d.infected_time) == ESIM_INFECTED;
+            inf = status_in_chunk(d, w, t0, j) == ESIM_INFECTED;
             key = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
         }
         uint32_t rank = 0;
@@ -757,7 +894,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
         }
         if (lane < sz && k) {
             const uint32_t te = CW_TE(w);
-            if (!(w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_FLAGS)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE))) {   // not exposed before this bus
+            if (!(w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_KEEP)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) || j > CW_VAX_REL(w))) {   // not exposed before this bus, not Vaccinated by then
                 const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
                 if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
             }
@@ -857,7 +994,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
         for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
             const uint32_t c = d.route_riders[off + i];
             rs.s_key[i] = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
-            rs.s_inf[i] = status_of(CW_TE(d.cit[c]), s, d.exposed_time, d.infected_time) == ESIM_INFECTED ? 1 : 0;
+            rs.s_inf[i] = status_in_chunk(d, d.cit[c], t0, j) == ESIM_INFECTED ? 1 : 0;
         }
         for (uint32_t i = threadIdx.x; i < sz / d.bus_capacity + 1u; i += TPB) rs.s_cnt[i] = 0u;
         __syncthreads();
@@ -875,7 +1012,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
             if (!k) continue;
             const uint32_t c = d.route_riders[off + i];
             const uint32_t w = d.cit[c], te = CW_TE(w);
-            if (w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_FLAGS)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE)) continue;   // exposed before this bus
+            if (w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_KEEP)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) || j > CW_VAX_REL(w)) continue;   // exposed before this bus, or Vaccinated by then
             const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
             if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
         }
@@ -887,16 +1024,45 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
 // exposures (k_chunk_books does it itself otherwise).
 __global__ __launch_bounds__(TPB) void k_chunk_count(Dev d)
 {
-    if (!d.ctrl->chunk_parallel || d.ctrl->chunk_ok == 0u) return;
+    Ctrl *ctrl = d.ctrl;
+    if (!ctrl->chunk_parallel || ctrl->chunk_ok == 0u) return;
     const uint32_t tid = blockIdx.x * TPB + threadIdx.x, r = tid & (SUBQ - 1u), step = (gridDim.x * TPB) / SUBQ;
     const uint32_t n_new = min(ld(&d.hot[(HOT_NEWEXP + r) * HOT_STRIDE]), d.newexp_cap);
     const uint32_t *list = d.newexp + (size_t)r * d.newexp_cap;
+    const uint32_t t0 = ctrl->chunk_t0;
     // (exp_step of the chunk's steps is zero from reset / from nobody having written it: steps are visited once)
     for (uint32_t i = tid / SUBQ; i < n_new; i += step) {
         const uint32_t w = d.cit[list[i]];
         const uint32_t s = CW_TE(w) - TE_BIAS;
         atomicAdd(&d.exp_step[2u * s + ((w & CW_BUS_EXPOSED) ? 1u : 0u)], 1u);
+        // exposed on a bus although the plan vaccinates it later in the chunk: from this step on the plan is void (k_chunk_vax)
+        if ((w & CW_BUS_EXPOSED) && CW_VAX_REL(w) != CW_VAX_NONE) atomicMin(&ctrl->chunk_cut, s - t0);
     }
+    if (!ctrl->vax_chunk) return;
+    // What the chunk's vaccinations do to the census of its later steps, from the words as the draws left them: one thread per
+    // planned citizen, only the step that won counts.  A citizen vaccinated at the end of step j is Vaccinated from step j + 1
+    // on instead of what its exposure step says (Susceptible; Exposed up to e_last; Infected up to i_last; Recovered after).
+    // Difference arrays over the steps; events at or after a cut only touch steps that are not committed.
+    __shared__ int dl[4][FREE_MAX + 2];
+    for (uint32_t i = threadIdx.x; i < 4u * (FREE_MAX + 2u); i += TPB) (&dl[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t n = ctrl->chunk_ok;
+    for (uint32_t j = blockIdx.x; j < n; j += gridDim.x) {
+        const uint32_t cnt = d.vax_cnt[j];
+        for (uint32_t i = threadIdx.x; i < cnt; i += TPB) {
+            const uint32_t w = d.cit[d.vax_ev[(size_t)j * VACC_MAX_RATE + i]], te = CW_TE(w);
+            if (CW_VAX_REL(w) != j) continue;                                  // (j = n - 1 only moves the totals after the chunk: index n)
+            atomicAdd(&dl[3][j + 1u], 1);                                      // Vaccinated from j + 1 to the end
+            if (te == TE_SUSCEPTIBLE) { atomicSub(&dl[0][j + 1u], 1); continue; }
+            const int e_last = (int)te - (int)TE_BIAS + (int)d.exposed_time - (int)t0, i_last = e_last + 1 + (int)d.infected_time;
+            const int lo = (int)j + 1;
+            if (lo <= e_last) { atomicSub(&dl[1][lo], 1); atomicAdd(&dl[1][min(e_last, (int)n - 1) + 1], 1); }
+            const int ilo = max(lo, e_last + 1);
+            if (ilo <= i_last && ilo < (int)n) { atomicSub(&dl[2][ilo], 1); atomicAdd(&dl[2][min(i_last, (int)n - 1) + 1], 1); }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 4u * (FREE_MAX + 2u); i += TPB) { const int v = (&dl[0][0])[i]; if (v) atomicAdd(&d.vax_delta[i], (uint32_t)v); }
 }
 
 // The chunk's exposures enter the log grouped by step (after k_batch_finish wrote the offsets); the hash map and
@@ -912,10 +1078,34 @@ __global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d)
         const uint32_t tid = blockIdx.x * TPB + threadIdx.x, r = tid & (SUBQ - 1u), step = (gridDim.x * TPB) / SUBQ;
         const uint32_t n_new = min(d.hot[(HOT_PREV_NEWEXP + r) * HOT_STRIDE], d.newexp_cap);
         const uint32_t *list = d.newexp + (size_t)r * d.newexp_cap;
+        const uint32_t n_eff = ctrl->prev_n_eff;
         for (uint32_t i = tid / SUBQ; i < n_new; i += step) {
             const uint32_t m = list[i];
             const uint32_t te = CW_TE(d.cit[m]);
-            d.log[d.log_off[te] + atomicAdd(&d.cursor[te - TE_BIAS - t0], 1u)] = m;
+            if (te - TE_BIAS - t0 < n_eff) d.log[d.log_off[te] + atomicAdd(&d.cursor[te - TE_BIAS - t0], 1u)] = m;
+            else {
+                // exposed in a step that was not committed (a cut, or the disease was over before): Susceptible again
+                atomicOr(&d.cit[m], TE_SUSCEPTIBLE << CW_TE_SHIFT);
+                atomicAnd(&d.cit[m], ~CW_BUS_EXPOSED);
+            }
+        }
+        if (ctrl->prev_vax) {
+            // the planned vaccinations: those of committed steps happen (simulator.rs:551: whatever the citizen was, it is
+            // Vaccinated; an exposure step leaves the histogram as vaccinate() does), the others are forgotten
+            const uint32_t n = ctrl->prev_n;
+            for (uint32_t j = blockIdx.x; j < n; j += gridDim.x) {
+                const uint32_t cnt = d.vax_cnt[j];
+                for (uint32_t i = threadIdx.x; i < cnt; i += TPB) {
+                    const uint32_t c = d.vax_ev[(size_t)j * VACC_MAX_RATE + i];
+                    const uint32_t w = d.cit[c];
+                    if (CW_VAX_REL(w) != j) continue;                         // another step of the chunk won, or Vaccinated before
+                    if (j < n_eff) {
+                        const uint32_t te = CW_TE(w);
+                        if (te < TE_RECOVERED) atomicSub(&d.hist[te], 1u);
+                        d.cit[c] = CW_MAKE(TE_VACCINATED, w & (CW_BUS_EXPOSED | CW_FLAGS));
+                    } else atomicAnd(&d.cit[c], ~CW_VAX_MASK);
+                }
+            }
         }
     }
     // the hash slots (and spilled count vectors) of the ids that were handed out: a thread per (wavefront of k_chunk_marks,
@@ -942,15 +1132,20 @@ __global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d)
 // (body shared by the two launch forms below)
 // e: this chunk's exposure counts [2 * step of the chunk + (bus ? 1 : 0)] when the caller holds them (else d.exp_step has them);
 // lo_out: receives the first log position of every step of the chunk.
-__device__ __forceinline__ void batch_finish_body(const Dev &d, uint32_t t0, uint32_t n, const uint32_t *e = nullptr, uint32_t *lo_out = nullptr)
+// vax: the chunk ran under a vaccination programme with its vaccinations planned (k_chunk_vax): the census moves by the
+// prefix sums of Dev::vax_delta, and only the steps before Ctrl::chunk_cut are committed.  Returns the steps committed.
+__device__ __forceinline__ uint32_t batch_finish_body(const Dev &d, uint32_t t0, uint32_t n, const uint32_t *e = nullptr, uint32_t *lo_out = nullptr, bool vax = false,
+                                                       bool marks_left = true)
 {
     __shared__ uint32_t P[BF_WIN + 1];                 // P[i + 1] = sum of H[0..i], P[0] = 0
     __shared__ uint32_t wtmp[FIN_TPB / 64];
     __shared__ uint32_t n_eff_s;
+    __shared__ uint32_t cum[5][FREE_MAX + 2];          // prefix sums of the vaccination deltas (S, E, I, V) and of the bus exposures
     Ctrl *ctrl = d.ctrl;
     const uint32_t tid = threadIdx.x;
     const int et = (int)d.exposed_time, it = (int)d.infected_time;
     const int base_idx = (int)(t0 + TE_BIAS) - et - 1 - it;              // lowest histogram entry any census of the chunk reads
+    const uint32_t n_cut = vax ? min(n, ld(&ctrl->chunk_cut)) : n;
     // H[i] = citizens exposed in "step" base_idx + i: the histogram before the chunk, this chunk's exposure counters inside it
     {
         const int k = base_idx + (int)tid;
@@ -958,11 +1153,20 @@ __device__ __forceinline__ void batch_finish_body(const Dev &d, uint32_t t0, uin
         if (k >= (int)(t0 + TE_BIAS)) { const uint32_t j = (uint32_t)(k - (int)(t0 + TE_BIAS)); if (j < n) h = e ? e[2u * j] + e[2u * j + 1u] : d.exp_step[2u * (t0 + j)] + d.exp_step[2u * (t0 + j) + 1u]; }
         else if (k >= 0) h = d.hist[k];
         P[tid + 1] = h;
-        if (tid == 0) { P[0] = 0u; n_eff_s = n; }
+        if (tid == 0) { P[0] = 0u; n_eff_s = n_cut; }
+        if (tid < 5u) {
+            // cum[q][i] = sum of delta[q][0..i] (i.e. what applies to step i); cum[4][i] = bus exposures of steps < i
+            uint32_t a = 0;
+            for (uint32_t i = 0; i < FREE_MAX + 2u; ++i) {
+                if (tid < 4u) { a += vax ? ld(&d.vax_delta[tid * (FREE_MAX + 2u) + i]) : 0u; cum[tid][i] = a; }
+                else { cum[4][i] = a; if (i < n) a += e ? e[2u * i + 1u] : d.exp_step[2u * (t0 + i) + 1u]; }
+            }
+        }
     }
     __syncthreads();
     block_scan_1024(P + 1, wtmp);
-    const uint32_t S0 = ctrl->n_susceptible, V = ctrl->n_vaccinated, run0 = d.log_off[t0 + TE_BIAS];
+    const uint32_t S0 = ctrl->n_susceptible, V0 = ctrl->n_vaccinated, run0 = d.log_off[t0 + TE_BIAS];
+    const uint32_t elig0 = ctrl->elig_count;
     const int top0 = (int)(t0 + TE_BIAS) - base_idx;                      // index of hist[t0 + TE_BIAS] in H
     esim_step_result r;
     uint32_t exps = 0;
@@ -970,18 +1174,23 @@ __device__ __forceinline__ void batch_finish_body(const Dev &d, uint32_t t0, uin
         const uint32_t s = t0 + tid;
         const int ts = top0 + (int)tid;                                   // index of this step's own entry
         exps = P[ts + 1] - P[ts];
-        const uint32_t S = S0 - (P[ts] - P[top0]);                         // Susceptible before this step's exposures
-        const uint32_t E = P[ts] - P[ts - et];                             // exposed in steps s - et .. s - 1 (census precedes exposures)
-        const uint32_t I = P[ts - et] - P[ts - et - 1 - it];
+        const uint32_t S = S0 - (P[ts] - P[top0]) + cum[0][tid];           // Susceptible before this step's exposures
+        const uint32_t E = P[ts] - P[ts - et] + cum[1][tid];               // exposed in steps s - et .. s - 1 (census precedes exposures)
+        const uint32_t I = P[ts - et] - P[ts - et - 1 - it] + cum[2][tid];
+        const uint32_t V = V0 + cum[3][tid];
         r.time_step = s;
-        if (exps > S) ctrl->error = (uint32_t)(-ESIM_ESIM);               // citizen_exposed underflow, statistics.rs:275-287
+        if (exps > S && tid < n_cut) ctrl->error = (uint32_t)(-ESIM_ESIM); // citizen_exposed underflow, statistics.rs:275-287
         r.susceptible = S - exps; r.exposed = E + exps; r.infected = I;
         r.recovered = d.n - S - V - E - I; r.vaccinated = V;
         r.exposures_building = e ? e[2u * tid] : d.exp_step[2u * s]; r.exposures_bus = e ? e[2u * tid + 1u] : d.exp_step[2u * s + 1u];
-        if (e) { d.exp_step[2u * s] = r.exposures_building; d.exp_step[2u * s + 1u] = r.exposures_bus; }
+        if (e || tid >= n_cut) {                                          // (steps that are not committed will be counted again)
+            d.exp_step[2u * s] = tid < n_cut ? r.exposures_building : 0u; d.exp_step[2u * s + 1u] = tid < n_cut ? r.exposures_bus : 0u;
+        }
         if (lo_out) lo_out[tid] = run0 + (P[ts] - P[top0]);
-        r.lockdown = d.dec[tid + 1u].lockdown; r.vaccination_active = 0u; r.mask_status = d.dec[tid + 1u].mask;
-        r.n_riders = d.dec[tid].bus_dir ? d.n_pt : 0u; r.vaccinated_now = 0u; r.eligible_count = 0u;
+        r.lockdown = d.dec[tid + 1u].lockdown; r.vaccination_active = vax ? 1u : 0u; r.mask_status = d.dec[tid + 1u].mask;
+        r.n_riders = d.dec[tid].bus_dir ? d.n_pt : 0u;
+        r.vaccinated_now = vax ? d.vax_now[tid] : 0u;
+        r.eligible_count = vax ? elig0 - cum[4][tid + 1u] : 0u;            // after this step's bus exposures (simulator.rs:447-449)
         r.disease_exists = (r.exposed != 0u || r.infected != 0u || r.susceptible != 0u) ? 1u : 0u;   // statistics.rs:289-291
         r.reserved = 0u;
         if (!r.disease_exists && ctrl->stop_when_done) atomicMin(&n_eff_s, tid + 1u);
@@ -996,17 +1205,25 @@ __device__ __forceinline__ void batch_finish_body(const Dev &d, uint32_t t0, uin
         if (s <= d.max_steps) d.records[s] = r;
     }
     if (tid == 0) {
-        ctrl->n_susceptible = S0 - (P[top0 + (int)n_eff] - P[top0]);
+        ctrl->n_susceptible = S0 - (P[top0 + (int)n_eff] - P[top0]) + cum[0][n_eff];
+        ctrl->n_vaccinated = V0 + cum[3][n_eff];
+        if (vax) ctrl->elig_count = elig0 - cum[4][n_eff];
         ctrl->log_len = run0 + (P[top0 + (int)n_eff] - P[top0]);
         ctrl->t = t0 + n_eff; ctrl->steps_done = t0 + n_eff - 1u;
-        if (n_eff < n) ctrl->finished = 1u;
-        ctrl->lockdown = d.dec[n_eff].lockdown; ctrl->mask = d.dec[n_eff].mask;
-        ctrl->at_work = d.dec[n_eff - 1u].at_work; ctrl->bus_dir = d.dec[n_eff - 1u].bus_dir;
-        // ring slots: only the last step's marks stay (the next exposure pass clears them)
-        const uint32_t keep = (t0 + n - 1u) & (MARK_SLOTS - 1u);
+        if (n_eff < n_cut) ctrl->finished = 1u;
+        else if (n_cut < n) { ctrl->need_seq = 1u; ctrl->vax_cuts += 1u; }   // the step of the cut runs in the sequential form
+        if (n_eff) {
+            ctrl->lockdown = d.dec[n_eff].lockdown; ctrl->mask = d.dec[n_eff].mask;
+            ctrl->at_work = d.dec[n_eff - 1u].at_work; ctrl->bus_dir = d.dec[n_eff - 1u].bus_dir;
+        }
+        // ring slots: a chunk run step by step leaves the marks of its last step (the next exposure pass clears them); a chunk
+        // drawn in one pass leaves none -- and the lists k_chunk_marks emptied for it must not keep their old lengths, or a
+        // sequential step that comes back to that slot would walk stale entries (a route ranked twice at once)
+        const uint32_t keep = marks_left ? ((t0 + n - 1u) & (MARK_SLOTS - 1u)) : MARK_SLOTS;
         for (uint32_t z = 0; z < MARK_SLOTS; ++z)
             if (z != keep) { ctrl->n_touched_bld[z] = 0u; ctrl->n_touched_room[z] = 0u; ctrl->n_touched_route[z] = 0u; ctrl->n_touched_route_big[z] = 0u; }
     }
+    return n_eff;
 }
 
 __global__ __launch_bounds__(FIN_TPB) void k_batch_finish(Dev d, uint32_t t0, uint32_t n)
@@ -1055,12 +1272,14 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
     } else if (tid < 2u * n) e_cnt[tid] = d.exp_step[2u * t0 + tid];           // k_chunk_count made them
     __syncthreads();
     const uint32_t pb1 = PROF_NOW();
-    batch_finish_body(d, t0, n, e_cnt, lo_s);
+    const bool vax = ld(&ctrl->vax_chunk) != 0u;                              // (planned chunks always take the wide form: fused == 0)
+    const uint32_t n_eff = batch_finish_body(d, t0, n, e_cnt, lo_s, vax, false);
     const uint32_t pb2 = PROF_NOW();
     if (!fused) {
         // k_chunk_scatter runs after this kernel, i.e. after the next chunk's decisions have reset what it reads: keep a copy
         if (tid < SUBQ) d.hot[(HOT_PREV_NEWEXP + tid) * HOT_STRIDE] = n_new;   // (thread r < 64 read sub-list r's length above)
-        if (tid == 0) { ctrl->prev_t0 = t0; ctrl->prev_n_items = n_items; ctrl->prev_per_wave = ld(&ctrl->items_per_wave); }
+        if (tid == 0) { ctrl->prev_t0 = t0; ctrl->prev_n_items = n_items; ctrl->prev_per_wave = ld(&ctrl->items_per_wave);
+                        ctrl->prev_n = n; ctrl->prev_n_eff = n_eff; ctrl->prev_vax = vax ? 1u : 0u; ctrl->vax_chunk = 0u; }
         // ... and start its per-step write cursors from zero: the scatter of the chunk before this one ran after the
         // decision step that last cleared them
         if (tid < FREE_MAX) d.cursor[tid] = 0u;

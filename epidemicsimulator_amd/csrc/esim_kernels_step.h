@@ -531,6 +531,7 @@ __device__ __forceinline__ void finish_phase(const Dev &d, Ctrl *ctrl, int shard
         ctrl->n_touched_bld[q] = 0u; ctrl->n_touched_room[q] = 0u; ctrl->n_touched_route[q] = 0u; ctrl->n_touched_route_big[q] = 0u;
         ctrl->n_riders = 0u;
         for (int i = 0; i < 5; ++i) ctrl->counts[i] = 0u;
+        ctrl->need_seq = 0u;                                                // (a cut chunk asked for this step in this form, k_chunk_vax)
         ctrl->t = t + 1u;
     }
     __syncthreads();

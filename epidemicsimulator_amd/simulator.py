@@ -127,33 +127,34 @@ class Simulator:
         stop_when_done), which produces the same records without a host round trip per step."""
         start = time.time()
         max_time_step = int(self.params.max_steps)
+        # A context that has already run (step(), run(), load_checkpoint()) continues from its own clock: the loop index of
+        # simulator.rs:114 is the absolute step index self._steps, so the budget and the progress cadence stay the run's.
         if self.record_timings:
-            for time_step in range(max_time_step):
+            while self._steps < max_time_step:
+                time_step = self._steps
                 if not self.step():
                     break
                 if time_step % DEBUG_ITERATION_PRINT == 0:
                     self._progress(start)
                     start = time.time()
         else:
-            done = 0
-            while done < max_time_step:
-                # the next progress line follows the step with index done' = 0 (mod 50)
-                n = 1 if done == 0 else min(DEBUG_ITERATION_PRINT, max_time_step - done)
+            while self._steps < max_time_step:
+                # the next progress line follows the step with index 0 (mod 50)
+                done = self._steps
+                n = 1 if done == 0 else DEBUG_ITERATION_PRINT - (done - 1) % DEBUG_ITERATION_PRINT
+                n = min(n, max_time_step - done)
                 t_block = time.time()
                 arr = self.run(n, stop_when_done=True)
                 if len(arr) == 0:
                     break
-                # the phases of simulator.rs:137-143 do not exist separately in a device-resident run: only the
-                # total is known, as the block's wall time spread over its steps
+                # the phases of simulator.rs:137-143 do not exist separately in a device-resident run: only the total is
+                # known (the block's wall time spread over its steps), so the phase keys are left out of those entries
                 per_step = (time.time() - t_block) / len(arr)
-                self.statistics_recorder.timer_entries.extend(
-                    {"Generate Exposures": None, "Apply Exposures": None, "Apply Interventions": None, "total": per_step}
-                    for _ in range(len(arr)))
-                done += len(arr)
+                self.statistics_recorder.timer_entries.extend({"total": per_step} for _ in range(len(arr)))
                 self.last = {k: int(arr[k][-1]) for k in arr.dtype.names}
                 if not self.last["disease_exists"]:
                     break
-                if (done - 1) % DEBUG_ITERATION_PRINT == 0:
+                if (self._steps - 1) % DEBUG_ITERATION_PRINT == 0:
                     self._progress(start)
                     start = time.time()
         self.statistics_recorder.dump_to_file(output_name, self.exposures_per_output_area(self.area_codes))

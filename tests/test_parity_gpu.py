@@ -27,10 +27,11 @@ def assert_same_state(sim, orc):
         assert (g[k] == o[k]).all(), k
 
 
-# every scenario runs five ways: time-parallel chunks (default: all steps of a chunk drawn in one pass until a
-# vaccination programme starts, then sequential steps), chunks as one kernel per step, and sequential steps only with the default hand-over between the persistent
-# single-workgroup kernel and the multi-workgroup kernels, multi-workgroup kernels only, persistent kernel only
-SMALL_LIMITS = ("tp", "pipe", None, 0, 1 << 30)
+# every scenario runs six ways: time-parallel chunks all the way (default: all steps of a chunk drawn in one pass, under a
+# vaccination programme with the chunk's vaccinations planned ahead), time-parallel chunks until a programme starts and
+# sequential steps from there, chunks as one kernel per step, and sequential steps only with the default hand-over between the
+# persistent single-workgroup kernel and the multi-workgroup kernels, multi-workgroup kernels only, persistent kernel only
+SMALL_LIMITS = ("vax", "tp", "pipe", None, 0, 1 << 30)
 
 
 def run_both(pop, steps, check_state_every=None, small_limits=SMALL_LIMITS, **params):
@@ -41,8 +42,10 @@ def run_both(pop, steps, check_state_every=None, small_limits=SMALL_LIMITS, **pa
 def _run_both(pop, steps, check_state_every, small_limit, **params):
     ep = _lib.default_params(**params)
     sim = Simulator(pop, ep)
-    if small_limit == "tp":
-        sim.set_pipeline(2)                       # time-parallel chunks (default)
+    if small_limit == "vax":
+        sim.set_pipeline(3)                       # time-parallel chunks, also under a vaccination programme (default)
+    elif small_limit == "tp":
+        sim.set_pipeline(2)                       # time-parallel chunks until a vaccination programme starts
     elif small_limit == "pipe":
         sim.set_pipeline(1)                       # one kernel per step
     else:
@@ -239,6 +242,29 @@ def test_checkpoint_resume_continues_bit_for_bit(tmp_path):
     with pytest.raises(_lib.EsimError, match="another population"):
         other.load_checkpoint(path)
     other.close(); whole.close()
+
+
+def test_simulate_after_a_resume_finishes_the_same_run(tmp_path, capsys):
+    # simulate() on a context that has already run (here: resumed from a checkpoint at step 330 of 500) continues from the
+    # context's clock: it must stay inside the step budget and write the files of the uninterrupted run
+    import json
+    pop = Population.synthetic("york", n_citizens=6000, n_areas=20, citizens_per_school=3000, n_seeds=12)
+    ep = _lib.default_params(max_steps=500, **AGGRESSIVE)
+    whole = Simulator(pop, ep)
+    whole.simulate(str(tmp_path) + "/whole/")
+    lines_whole = capsys.readouterr().out.count("Completed  50 time steps")
+    a = Simulator(pop, ep)
+    a.run(330)
+    a.save_checkpoint(str(tmp_path / "c.bin"))
+    a.close()
+    b = Simulator(pop, ep)
+    b.load_checkpoint(str(tmp_path / "c.bin"))
+    b.simulate(str(tmp_path) + "/resumed/")
+    lines_resumed = capsys.readouterr().out.count("Completed  50 time steps")
+    for name in ("global_stats.json", "exposures.json"):
+        assert json.load(open(str(tmp_path) + "/whole/" + name)) == json.load(open(str(tmp_path) + "/resumed/" + name)), name
+    assert lines_whole == 10 and lines_resumed == 3               # after the steps with index 0, 50, ..., 450 / 350, 400, 450
+    whole.close(); b.close()
 
 
 def test_reset_reproduces_the_run():

@@ -25,7 +25,7 @@ print(params, steps, cse)
 ep = _lib.default_params(**params)
 orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
 want = orc.run(steps)
-for name, level, lim in (("tp", 2, None), ("pipe", 1, None), ("seq", 0, None), ("seq-multi", 0, 0), ("seq-small", 0, 1 << 30)):
+for name, level, lim in (("vax", 3, None), ("tp", 2, None), ("pipe", 1, None), ("seq", 0, None), ("seq-multi", 0, 0), ("seq-small", 0, 1 << 30)):
     sim = Simulator(pop, ep)
     sim.set_pipeline(level)
     if lim is not None: sim.set_small_step_limit(lim)
@@ -47,7 +47,7 @@ for name, level, lim in (("tp", 2, None), ("pipe", 1, None), ("seq", 0, None), (
 # ---- the one-pass form again, chunk by chunk, down to the first citizen that differs
 if "--trace" in sys.argv:
     for attempt in range(6):
-        sim = Simulator(pop, ep); sim.set_pipeline(2)
+        sim = Simulator(pop, ep); sim.set_pipeline(3)
         orc2 = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
         done = 0
         prev_o = orc2.state()
