@@ -88,7 +88,7 @@ class SynthSpec(C.Structure):
 SYMBOLS = [
     "esim_default_params", "esim_create", "esim_upload_population", "esim_reset", "esim_step",
     "esim_run", "esim_step_begin", "esim_step_exposures", "esim_step_finish",
-    "esim_exchange_buffer", "esim_future_infected", "esim_run_free", "esim_free_begin", "esim_free_enqueue", "esim_free_collect", "esim_set_pipeline", "esim_chunk_timing", "esim_pipeline_timing",
+    "esim_exchange_buffer", "esim_future_infected", "esim_run_free", "esim_free_begin", "esim_free_enqueue", "esim_free_collect", "esim_set_pipeline", "esim_chunk_timing", "esim_vax_chunk_stats", "esim_pipeline_timing",
     "esim_read_records", "esim_stream", "esim_set_stream",
     "esim_set_exchange_buffer", "esim_synchronize",
     "esim_download_state", "esim_download_exposure_log", "esim_checkpoint_size", "esim_checkpoint_save", "esim_checkpoint_restore", "esim_enable_phase_timing", "esim_phase_timings",
@@ -130,6 +130,7 @@ def load():
         "esim_free_collect": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
         "esim_set_pipeline": (C.c_int, [vp, C.c_int]),
         "esim_chunk_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "esim_vax_chunk_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "esim_pipeline_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "esim_read_records": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(StepResult)]),
         "esim_stream": (C.c_int, [vp, pvp]),

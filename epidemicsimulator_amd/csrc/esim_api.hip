@@ -670,6 +670,7 @@ void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
     hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, 0, 0, (uint32_t)c->xf_n, limit_t);
     hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_vax_final, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d);
 }
 
 // One pipelined chunk.  Precondition: k_future ran for the current step (and, when sharded, buffer F was
@@ -741,7 +742,7 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             // bursts of planned chunks; whatever stops one (a cut: the step at ctrl->t must run sequentially; no plan possible;
             // a chunk that does not fit the one-pass form) is answered with sequential steps, more of them when it keeps happening
             const uint32_t first = c->host_t, limit_t = first + remaining - 1u;
-            const uint32_t bursts = std::min<uint32_t>((remaining + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n, vax_fail ? 1u : 8u);
+            const uint32_t bursts = vax_fail ? 1u : std::min<uint32_t>((remaining + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n + 1u, 8u);   // (one more than fit: cuts)
             const bool tk = c->kernel_timing;
             if (tk) { if (!c->cev[0]) { (void)hipEventCreate(&c->cev[0]); (void)hipEventCreate(&c->cev[1]); } HIP_TRY(c, hipEventRecord(c->cev[0], c->stream)); }
             for (uint32_t g = 0; g < bursts; ++g) enqueue_vax_chunk(c, limit_t);
@@ -758,8 +759,11 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             c->host_t = h.t; total += done; remaining -= done;
             if (h.finished && allow_early_stop) break;
             if (remaining == 0) break;
-            if (done >= std::min<uint32_t>(remaining + done, bursts * (uint32_t)c->xf_n)) { vax_fail = 0; continue; }
-            vax_fail = done ? 1u : std::min<uint32_t>(vax_fail + 1u, 8u);
+            if (done) { vax_fail = 0; continue; }                       // (cut chunks advance less; the next one starts at the cut)
+            if (std::getenv("ESIM_DEBUG"))
+                std::fprintf(stderr, "[esim] vax burst without progress at t=%u: chunk_ok=%u parallel=%u vax_chunk=%u cut=%u pairs=%u fits_flag=%u elig=%u bursts=%u\n",
+                             h.t, h.chunk_ok, h.chunk_parallel, h.vax_chunk, h.chunk_cut, h.chunk_pairs, 0u, h.elig_count, bursts);
+            vax_fail = std::min<uint32_t>(vax_fail + 1u, 8u);
             uint32_t seq = 0;
             const uint32_t want = std::min<uint32_t>(remaining, vax_fail <= 1u ? 1u : (vax_fail <= 3u ? 8u : (uint32_t)c->xf_n));
             if ((rc = run_sequential(c, want, allow_early_stop, &seq))) return rc;
@@ -957,6 +961,15 @@ extern "C" int esim_set_pipeline(esim_ctx *ctx, int enable)
     c->pipeline = enable != 0;            // 0: sequential steps only
     c->time_parallel = enable >= 2;       // 1: one kernel per step (k_pipe); 2: all steps of a chunk in one pass
     c->vax_chunks = enable >= 3;          // 3 (default): ... also while a vaccination programme runs, its vaccinations planned per chunk
+    return ESIM_OK;
+}
+
+extern "C" int esim_vax_chunk_stats(esim_ctx *ctx, uint64_t *steps, uint64_t *cuts)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c) return ESIM_EINVAL;
+    if (steps) *steps = c->vax_chunk_steps;
+    if (cuts) *cuts = c->vax_chunk_cuts;
     return ESIM_OK;
 }
 

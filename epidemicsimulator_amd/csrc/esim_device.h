@@ -11,6 +11,9 @@
 // bits 17..11  vax : only inside a time-parallel chunk that runs under a vaccination programme: 127 - j when the citizen
 //                   is set Vaccinated at the END of step j of the chunk (simulator.rs:524-553), 0 = not in this chunk.  The
 //                   earliest such step wins by atomicMax; k_chunk_scatter turns it into te = TE_VACCINATED and clears it.
+// bit  10      plan_skip : the citizen is Susceptible and WILL be exposed on public transport in the step at ctrl->t (a chunk was
+//                   cut there, k_chunk_vax): it leaves citizens_eligible_for_vaccine in that step, so the next plan must not
+//                   choose it.  Any exposure drops the bit.
 // bits 7..0    static flags (below)
 // te sits in the most significant bits and Susceptible is the largest te, so "exposed at the earliest step
 // at which any draw succeeds; a building beats a bus within a step" is one atomicMin on this word.
@@ -24,6 +27,7 @@
 #define CW_VAX_MASK    (0x7Fu << CW_VAX_SHIFT)
 #define CW_KEEP        (CW_FLAGS | CW_VAX_MASK)            // what an exposure inside a chunk leaves as it is
 #define CW_VAX_NONE    0xFFFFFFFFu
+#define CW_PLAN_SKIP   (1u << 10)
 // step of the chunk at whose end the citizen becomes Vaccinated (CW_VAX_NONE: not in this chunk)
 #define CW_VAX_REL(w)  ((((w) >> CW_VAX_SHIFT) & 0x7Fu) ? 127u - (((w) >> CW_VAX_SHIFT) & 0x7Fu) : CW_VAX_NONE)
 #define CW_VAX_FIELD(j) ((127u - (j)) << CW_VAX_SHIFT)
@@ -92,9 +96,11 @@ struct Ctrl {
     uint32_t vax_chunk;         // 1: the chunk in preparation has its vaccinations planned (events in Dev::vax_ev, fields in the words)
     uint32_t chunk_cut;         // first step of the chunk (relative) that must NOT be committed: a citizen exposed on a bus there had been
                                 // planned for vaccination at or after it (it left the eligible set, simulator.rs:447-449) -- FREE_MAX + 1: none
-    uint32_t need_seq;          // the step at ctrl->t must run in the sequential form (set with a cut, cleared by k_finish)
+    uint32_t need_seq;          // (unused: the step of a cut needs no special form, see CW_PLAN_SKIP)
+    uint32_t prev_cut;          // the chunk k_chunk_scatter is finishing was cut at prev_n_eff
     uint32_t prev_n, prev_n_eff, prev_vax; // the chunk k_chunk_scatter is finishing: its length, the steps committed, whether it was planned
     uint32_t vax_cuts;          // diagnostics: chunks that were cut short
+    uint32_t vax_planned, prev_planned; // steps the plan of the chunk in preparation / being finished covers (>= the chunk's length)
 };
 
 // A deferred unit of a long member list: UNIT_PAIRS (member, marked step) pairs from pair p_lo on.  code = kind << 30 | p_lo

@@ -176,6 +176,18 @@ __device__ __forceinline__ void decide_body(const Dev &d, uint32_t max_ahead, ui
         const uint32_t msk = (pre[r] >> (2u * mask_init)) & 3u;
         mine[r] = Decision{ lockd[r], msk, at_work, bus_dir };
     }
+    if (allow_parallel) {
+        // A one-pass chunk registers at most CHUNK_BUS_STEPS steps with riders on a bus (two a day -- unless a lockdown froze
+        // them there, Q8: then every step is one).  Rather than give up the form, the chunk ends in front of the step that
+        // would be one too many.
+        const unsigned long long b0 = __ballot(lane < n_ok && mine[0].bus_dir != 0u), b1 = __ballot(64u + lane < n_ok && mine[1].bus_dir != 0u);
+        const unsigned long long lt_ = (1ull << lane) - 1ull;
+        const uint32_t before0 = (uint32_t)__popcll(b0 & lt_), before1 = (uint32_t)(__popcll(b0) + __popcll(b1 & lt_));
+        const unsigned long long over0 = __ballot(((b0 >> lane) & 1ull) && before0 == CHUNK_BUS_STEPS);
+        const unsigned long long over1 = __ballot(((b1 >> lane) & 1ull) && before1 == CHUNK_BUS_STEPS);
+        if (over0) n_ok = (uint32_t)__ffsll((long long)over0) - 1u;
+        else if (over1) n_ok = 64u + (uint32_t)__ffsll((long long)over1) - 1u;
+    }
     // what is in force after the chunk = what would be in force during step n_ok, except that position and bus
     // are those of step n_ok - 1 (k_batch_finish reads them from there)
     if (lane < n_ok) d.dec[lane] = mine[0];
@@ -234,7 +246,9 @@ __global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32
 // (k_chunk_vax_adj for the Infected counts the decisions need, k_chunk_count for the records).  The plan is speculative in
 // one respect only: a citizen it chose for step j may be exposed on a bus in a step s <= j of this very chunk, which removes
 // it from the set before its turn.  k_chunk_count finds the earliest such step s* (Ctrl::chunk_cut); the chunk is then
-// committed up to s* - 1, step s* runs in the sequential form (which removes the citizen properly), and chunks resume.
+// committed up to s* - 1 and the next chunk starts AT s*.  What happens in step s* itself does not depend on the plan from s*
+// on, so everybody the cut chunk saw exposed on a bus in s* will be again: k_chunk_scatter marks them (CW_PLAN_SKIP) and the
+// next plan leaves them out -- it cannot be cut at s* again.
 __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead, uint32_t limit_t)
 {
     __shared__ FinishShared sm;
@@ -252,6 +266,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead
         d.vax_cnt[j] = 0u; d.vax_now[j] = 0u;
         if (j == 0) {
             ctrl->vax_chunk = plan ? 1u : 0u;
+            ctrl->vax_planned = plan ? n_ahead : 0u;
             ctrl->chunk_cut = FREE_MAX + 1u;
             for (uint32_t z = FREE_MAX; z < FREE_MAX + 2u; ++z) { d.xf_adj[z] = 0u; for (uint32_t q = 0; q < 4u; ++q) d.vax_delta[q * (FREE_MAX + 2u) + z] = 0u; }
         }
@@ -268,7 +283,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead
             const uint32_t i = base + tid * 4u + q;
             cj[q] = vacc_candidate(d, i, t);
             cw[q] = d.cit[cj[q]];
-            live[q] = eligible(cw[q], tstep);
+            live[q] = eligible(cw[q], tstep) && !(cw[q] & CW_PLAN_SKIP);
             slot[q] = 0;
             if (live[q]) {
                 uint32_t sl = (cj[q] * 2654435761u) >> 18;        // 14 bits
@@ -1084,27 +1099,11 @@ __global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d)
             const uint32_t te = CW_TE(d.cit[m]);
             if (te - TE_BIAS - t0 < n_eff) d.log[d.log_off[te] + atomicAdd(&d.cursor[te - TE_BIAS - t0], 1u)] = m;
             else {
-                // exposed in a step that was not committed (a cut, or the disease was over before): Susceptible again
-                atomicOr(&d.cit[m], TE_SUSCEPTIBLE << CW_TE_SHIFT);
+                // exposed in a step that was not committed (a cut, or the disease was over before): Susceptible again; on a bus in
+                // the very step of the cut: it will be again, and the next plan must know (CW_PLAN_SKIP)
+                const bool again = ctrl->prev_cut && te - TE_BIAS - t0 == n_eff && (d.cit[m] & CW_BUS_EXPOSED);
+                atomicOr(&d.cit[m], (TE_SUSCEPTIBLE << CW_TE_SHIFT) | (again ? CW_PLAN_SKIP : 0u));
                 atomicAnd(&d.cit[m], ~CW_BUS_EXPOSED);
-            }
-        }
-        if (ctrl->prev_vax) {
-            // the planned vaccinations: those of committed steps happen (simulator.rs:551: whatever the citizen was, it is
-            // Vaccinated; an exposure step leaves the histogram as vaccinate() does), the others are forgotten
-            const uint32_t n = ctrl->prev_n;
-            for (uint32_t j = blockIdx.x; j < n; j += gridDim.x) {
-                const uint32_t cnt = d.vax_cnt[j];
-                for (uint32_t i = threadIdx.x; i < cnt; i += TPB) {
-                    const uint32_t c = d.vax_ev[(size_t)j * VACC_MAX_RATE + i];
-                    const uint32_t w = d.cit[c];
-                    if (CW_VAX_REL(w) != j) continue;                         // another step of the chunk won, or Vaccinated before
-                    if (j < n_eff) {
-                        const uint32_t te = CW_TE(w);
-                        if (te < TE_RECOVERED) atomicSub(&d.hist[te], 1u);
-                        d.cit[c] = CW_MAKE(TE_VACCINATED, w & (CW_BUS_EXPOSED | CW_FLAGS));
-                    } else atomicAnd(&d.cit[c], ~CW_VAX_MASK);
-                }
             }
         }
     }
@@ -1122,6 +1121,31 @@ __global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d)
             for (uint32_t j = 0; j < FREE_MAX; ++j) d.vec[(size_t)h * FREE_MAX + j] = 0u;
         d.hkey[h] = HKEY_EMPTY;
         if (state) d.slot_state[h] = 0u;
+    }
+}
+
+// The planned vaccinations of the chunk k_chunk_scatter has just finished (a kernel of its own: the scatter reads the exposure
+// steps this one overwrites): those of committed steps happen (simulator.rs:551: whatever the citizen was, it is Vaccinated;
+// an exposure step leaves the histogram as vaccinate() does), the others are forgotten.
+__global__ __launch_bounds__(TPB) void k_chunk_vax_final(Dev d)
+{
+    Ctrl *ctrl = d.ctrl;
+    if (!ctrl->prev_vax) return;
+    const uint32_t n_eff = ctrl->prev_n_eff;
+    // (the plan may reach beyond the chunk: the decisions can end a chunk early, k_decide)
+    const uint32_t n = ctrl->prev_planned;
+    for (uint32_t j = blockIdx.x; j < n; j += gridDim.x) {
+        const uint32_t cnt = d.vax_cnt[j];
+        for (uint32_t i = threadIdx.x; i < cnt; i += TPB) {
+            const uint32_t c = d.vax_ev[(size_t)j * VACC_MAX_RATE + i];
+            const uint32_t w = d.cit[c];
+            if (CW_VAX_REL(w) != j) continue;                         // another step of the chunk won, or Vaccinated before
+            if (j < n_eff) {
+                const uint32_t te = CW_TE(w);
+                if (te < TE_RECOVERED) atomicSub(&d.hist[te], 1u);
+                d.cit[c] = CW_MAKE(TE_VACCINATED, w & (CW_BUS_EXPOSED | CW_FLAGS));
+            } else atomicAnd(&d.cit[c], ~CW_VAX_MASK);
+        }
     }
 }
 
@@ -1211,7 +1235,8 @@ __device__ __forceinline__ uint32_t batch_finish_body(const Dev &d, uint32_t t0,
         ctrl->log_len = run0 + (P[top0 + (int)n_eff] - P[top0]);
         ctrl->t = t0 + n_eff; ctrl->steps_done = t0 + n_eff - 1u;
         if (n_eff < n_cut) ctrl->finished = 1u;
-        else if (n_cut < n) { ctrl->need_seq = 1u; ctrl->vax_cuts += 1u; }   // the step of the cut runs in the sequential form
+        else if (n_cut < n) ctrl->vax_cuts += 1u;
+        ctrl->prev_cut = (n_eff == n_cut && n_cut < n) ? 1u : 0u;
         if (n_eff) {
             ctrl->lockdown = d.dec[n_eff].lockdown; ctrl->mask = d.dec[n_eff].mask;
             ctrl->at_work = d.dec[n_eff - 1u].at_work; ctrl->bus_dir = d.dec[n_eff - 1u].bus_dir;
@@ -1249,7 +1274,11 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
     const uint32_t tid = threadIdx.x;
     const uint32_t pb0 = PROF_NOW();
     if (!ctrl->chunk_parallel || ctrl->chunk_ok == 0u) {
-        if (tid == 0) ctrl->chunk_done = 0u;
+        if (tid == 0) {
+            ctrl->chunk_done = 0u;
+            // a plan was made but the chunk does not run: k_chunk_vax_final takes the plan's fields out of the words again
+            ctrl->prev_vax = ld(&ctrl->vax_chunk); ctrl->prev_n_eff = 0u; ctrl->prev_planned = ld(&ctrl->vax_planned); ctrl->vax_chunk = 0u;
+        }
         // a sharded burst all-reduces buffer F in place before every chunk: it must hold THIS shard's census again, whether
         // or not the chunk ran
         if (do_next == 2) future_body(d, max_ahead, limit_t, win, wtmp);
@@ -1279,7 +1308,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
         // k_chunk_scatter runs after this kernel, i.e. after the next chunk's decisions have reset what it reads: keep a copy
         if (tid < SUBQ) d.hot[(HOT_PREV_NEWEXP + tid) * HOT_STRIDE] = n_new;   // (thread r < 64 read sub-list r's length above)
         if (tid == 0) { ctrl->prev_t0 = t0; ctrl->prev_n_items = n_items; ctrl->prev_per_wave = ld(&ctrl->items_per_wave);
-                        ctrl->prev_n = n; ctrl->prev_n_eff = n_eff; ctrl->prev_vax = vax ? 1u : 0u; ctrl->vax_chunk = 0u; }
+                        ctrl->prev_n = n; ctrl->prev_n_eff = n_eff; ctrl->prev_vax = vax ? 1u : 0u; ctrl->prev_planned = ld(&ctrl->vax_planned); ctrl->vax_chunk = 0u; }
         // ... and start its per-step write cursors from zero: the scatter of the chunk before this one ran after the
         // decision step that last cleared them
         if (tid < FREE_MAX) d.cursor[tid] = 0u;

@@ -321,6 +321,12 @@ class Simulator:
         _lib.check(self.lib.esim_chunk_timing(self._ctx, C.byref(ms), C.byref(ns), C.byref(nc)), self._ctx)
         return {"chunk_ms": ms.value, "steps": ns.value, "chunks": nc.value}
 
+    def vax_chunk_stats(self):
+        """Steps run as chunks under a vaccination programme and how many of those chunks were cut short."""
+        ns, nc = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self.lib.esim_vax_chunk_stats(self._ctx, C.byref(ns), C.byref(nc)), self._ctx)
+        return {"steps": ns.value, "cuts": nc.value}
+
     def pipeline_timing(self):
         ms, nt, nr = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
         _lib.check(self.lib.esim_pipeline_timing(self._ctx, C.byref(ms), C.byref(nt), C.byref(nr)), self._ctx)

@@ -164,7 +164,8 @@ int  esim_exchange_buffer(esim_ctx *ctx, int which /* 0 = A, 1 = B, 2 = F */, vo
  * writing the census ahead of the chunk after it into F -- and calls esim_free_collect(&done) once: done = steps the
  * burst advanced (the same on all shards).
  * esim_set_pipeline(ctx, level): 0 = sequential steps only; 1 = chunks run as one kernel per step (k_pipe);
- * 2 (default) = additionally, when the chunk's marks fit the hash map, ALL steps of a chunk are drawn in one
+ * 3 (default) = as 2, and chunks keep running under a vaccination programme (esim_vax_chunk_stats);
+ * 2 = additionally to 1, when the chunk's marks fit the hash map, ALL steps of a chunk are drawn in one
  * pass (a citizen's exposure step is the earliest step at which any of its draws succeeds -- one atomicMin on
  * the citizen word per successful draw).  esim_chunk_timing: device time (ms), steps and number of such chunks
  * since the last call (measured while kernel timing is enabled). */
@@ -175,6 +176,10 @@ int  esim_free_enqueue(esim_ctx *ctx);
 int  esim_free_collect(esim_ctx *ctx, uint32_t *n_done);
 int  esim_set_pipeline(esim_ctx *ctx, int level);
 int  esim_chunk_timing(esim_ctx *ctx, double *total_ms, uint64_t *steps, uint64_t *chunks);
+/* Steps run as time-parallel chunks under a vaccination programme (pipeline level 3: the chunk's vaccinations are planned
+ * ahead, simulator.rs:524-553 being a pure function of the step and of citizens_eligible_for_vaccine), and how many of those
+ * chunks were cut short because a citizen the plan had chosen left the eligible set on a bus first (simulator.rs:447-449). */
+int  esim_vax_chunk_stats(esim_ctx *ctx, uint64_t *steps, uint64_t *cuts);
 /* Record log read-back for split-phase runs (records first..first+n-1, 1-based time steps). */
 int  esim_read_records(esim_ctx *ctx, uint32_t first_step, uint32_t n, esim_step_result *out);
 /* The HIP stream all work of this context is enqueued on (hipStream_t as void*).  esim_set_stream

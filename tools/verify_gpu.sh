@@ -1,10 +1,8 @@
 #!/bin/bash
-# One GPU-box check of everything that has to stay true: the gpu test-suite, the benches against their goldens, a fuzz.
-# usage (on the GPU box, from the repo root): bash tools/verify_gpu.sh [fuzz_first_seed] [fuzz_count]
+# One GPU-box check of everything that has to stay true: the gpu test-suite, a fuzz, the benches against their goldens.
+# usage (on the GPU box, from the repo root): bash tools/verify_gpu.sh tag [fuzz_first_seed] [fuzz_count] [pytest -k expression]
+tag=${1:-x}
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest.log 2>&1; tail -3 gpurun_out/pytest.log
-for p in uk64m york yh_census; do
-  timeout -k 10 300 python bench.py --preset $p --steps 5000 --warmup 96 --cpu-steps 0 2>/dev/null > gpurun_out/bench_$p.json
-  python -c "import sys,json; d=json.load(open('gpurun_out/bench_$p.json')); print('$p', d['ms_per_step'], d.get('golden_check'), d['final_record'])"
-done
-timeout -k 10 300 python tools/fuzz_parity.py ${1:-2000} ${2:-200} | tail -1
+timeout -k 10 700 python -m pytest tests -m gpu -q -k "${4:-not nothing}" > gpurun_out/pytest_$tag.log 2>&1; tail -4 gpurun_out/pytest_$tag.log
+timeout -k 10 300 python tools/fuzz_parity.py ${2:-2000} ${3:-200} > gpurun_out/fuzz_$tag.log 2>&1; tail -1 gpurun_out/fuzz_$tag.log
+timeout -k 10 200 python tools/fuzz_parity.py 9000 12 --big > gpurun_out/fuzz_big_$tag.log 2>&1; tail -1 gpurun_out/fuzz_big_$tag.log
