@@ -340,8 +340,10 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     if ((rc = dev_alloc(c, &d.dec, FREE_MAX + 1))) return rc;
     // hash map of the time-parallel chunks: room for ~2 marks per (Infected, step) pair at < 1/2 load
     {
+        // slots for half the citizens (a quarter of that many items: a chunk in which up to ~3 % of the citizens are Infected
+        // still runs in the one-pass form), between 2^20 and 2^26; ~440 B per slot, most of it spill counters that stay cold
         uint32_t cap = 1u << 20;
-        while (cap < (1u << 24) && cap < N / 16u) cap <<= 1;
+        while (cap < (1u << 26) && cap < N / 2u) cap <<= 1;
         if (const char *e = std::getenv("ESIM_HASH_LOG2")) cap = 1u << std::min(28, std::max(4, std::atoi(e)));
         d.hcap = cap;
         d.items_cap = cap / 4u;                     // load factor <= 1/4; one count vector of FREE_MAX steps per item
