@@ -89,6 +89,7 @@ SYMBOLS = [
     "esim_default_params", "esim_create", "esim_upload_population", "esim_reset", "esim_step",
     "esim_run", "esim_step_begin", "esim_step_exposures", "esim_step_finish",
     "esim_exchange_buffer", "esim_future_infected", "esim_run_free", "esim_free_begin", "esim_free_enqueue", "esim_free_collect", "esim_set_pipeline", "esim_chunk_timing", "esim_vax_chunk_stats", "esim_pipeline_timing",
+    "esim_comm_unique_id", "esim_comm_init_rccl", "esim_comm_init_callback", "esim_comm_stats", "esim_run_sharded",
     "esim_read_records", "esim_stream", "esim_set_stream",
     "esim_set_exchange_buffer", "esim_synchronize",
     "esim_download_state", "esim_download_exposure_log", "esim_checkpoint_size", "esim_checkpoint_save", "esim_checkpoint_restore", "esim_enable_phase_timing", "esim_phase_timings",
@@ -97,6 +98,9 @@ SYMBOLS = [
     "esim_threshold_lut", "esim_synth_preset", "esim_synth_create", "esim_synth_create_shard", "esim_synth_free",
     "esim_shard_population",
 ]
+
+# esim_allreduce_fn: int (*)(void *user, int which, void *device_ptr, size_t n_u32)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
 
 _lib = None
 
@@ -123,6 +127,11 @@ def load():
         "esim_step_exposures": (C.c_int, [vp]),
         "esim_step_finish": (C.c_int, [vp, C.POINTER(StepResult)]),
         "esim_exchange_buffer": (C.c_int, [vp, C.c_int, pvp, C.POINTER(C.c_size_t)]),
+        "esim_comm_unique_id": (C.c_int, [vp, C.c_size_t]),
+        "esim_comm_init_rccl": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_int]),
+        "esim_comm_init_callback": (C.c_int, [vp, ALLREDUCE_FN, vp, C.c_int, C.c_int]),
+        "esim_comm_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+        "esim_run_sharded": (C.c_int, [vp, C.c_uint32, C.POINTER(C.c_uint32)]),
         "esim_future_infected": (C.c_int, [vp]),
         "esim_run_free": (C.c_int, [vp, C.c_uint32, C.POINTER(C.c_uint32)]),
         "esim_free_begin": (C.c_int, [vp, C.c_uint32]),

@@ -3,6 +3,9 @@
 // point that would compute fails with ESIM_ENODEVICE.
 #include "esim_kernels.hip"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -51,6 +54,11 @@ struct esim_ctx_impl {
     bool vax_chunks = true;            // time-parallel chunks also under a vaccination programme (their vaccinations planned ahead, k_chunk_vax)
     uint64_t vax_chunk_steps = 0, vax_chunk_cuts = 0;
     bool elig_seen = false;            // the last control block read back had an eligible set (a vaccination programme runs)
+    // the exchange between shards (esim_comm_*): RCCL owned by the library, or a caller's all-reduce
+    int comm_rank = 0, comm_world = 1;
+    ncclComm_t nccl = nullptr;
+    esim_allreduce_fn comm_fn = nullptr; void *comm_user = nullptr;
+    uint64_t comm_calls = 0;
     std::vector<hipEvent_t> fev; size_t fev_used = 0;                               // chunks of an open decoupled burst
     std::vector<hipEvent_t> pkev; size_t pkev_used = 0; uint64_t pipe_steps = 0;   // sampled k_pipe launches
     uint32_t small_max = 128;          // infected-slice length up to which the persistent single-workgroup kernel runs a step
@@ -59,6 +67,8 @@ struct esim_ctx_impl {
 };
 
 #define CTX(c) (reinterpret_cast<esim_ctx_impl *>(c))
+
+void comm_release(esim_ctx_impl *c);     // (defined with the exchange, below)
 
 int fail(esim_ctx_impl *c, int code, const std::string &msg)
 {
@@ -180,6 +190,7 @@ extern "C" int esim_create(const esim_params *p, esim_ctx **out)
 
 extern "C" void esim_destroy(esim_ctx *ctx)
 {
+    if (ctx) comm_release(CTX(ctx));
     if (!ctx) return;
     esim_ctx_impl *c = CTX(ctx);
     (void)hipSetDevice(c->P.device);
@@ -432,7 +443,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     HIP_TRY(c, hipMemset(d.prof_buf, 0, sizeof(uint32_t) * 16384 * 16));
 #endif
     c->xa_n = XA_HEADER + (size_t)d.n_shared_bld + d.n_shared_room;
-    c->xb_n = XB_HEADER + VACC_BATCH / 32u;
+    c->xb_n = XB_HEADER + VACC_WINDOW / 32u;
     if ((rc = dev_alloc(c, &d.xa, c->xa_n))) return rc;
     if ((rc = dev_alloc(c, &d.xb, c->xb_n))) return rc;
     c->xf_n = std::min<uint32_t>(FREE_MAX, c->P.exposed_time + 1u);
@@ -517,7 +528,7 @@ int enqueue_exposures(esim_ctx_impl *c, bool time_kernel)
     }
     (void)time_kernel;
     hipLaunchKernelGGL(k_expose, dim3(c->grid_expose), dim3(TPB), 0, c->stream, d);
-    if (d.n_shards > 1) hipLaunchKernelGGL(k_pack_b, dim3(VACC_BATCH / TPB), dim3(TPB), 0, c->stream, d);
+    if (d.n_shards > 1) hipLaunchKernelGGL(k_pack_b, dim3(VACC_WINDOW / TPB), dim3(TPB), 0, c->stream, d);
     if (c->phase_timing) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
     return ESIM_OK;
 }
@@ -876,6 +887,139 @@ extern "C" int esim_run(esim_ctx *ctx, uint32_t n_steps, int stop_when_done, esi
         HIP_TRY(c, hipMemcpy(out_array, &c->d.records[first], sizeof(esim_step_result) * done, hipMemcpyDeviceToHost));
     if (n_done) *n_done = done;
     return ESIM_OK;
+}
+
+// ---- the exchange between shards -----------------------------------------------------------------------------------
+// SUM all-reduces of small uint32 device buffers (the commuter exchange and the census).  Two transports:
+// RCCL over xGMI, with the communicator owned by the library and the collective enqueued on the context's own stream between
+// its kernels (no host synchronisation per step); or a caller-supplied function (tests on one GPU: gloo through the Python
+// binding), which is called with the stream drained.  librccl is loaded on first use, so a build without it still runs.
+namespace {
+
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+RcclApi &rccl()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api;
+    tried = true;
+    void *h = nullptr;
+    for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return api;
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+    api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.GetErrorString;
+    return api;
+}
+
+void comm_release(esim_ctx_impl *c)
+{
+    if (c->nccl && rccl().ok) rccl().CommDestroy(c->nccl);
+    c->nccl = nullptr;
+}
+
+// SUM all-reduce of exchange buffer `which` (0 A, 1 B, 2 F) over the shards, in place, ordered after everything enqueued so far.
+int exchange(esim_ctx_impl *c, int which)
+{
+    Dev &d = c->d;
+    uint32_t *buf = which == 2 ? d.xf : which ? d.xb : d.xa;
+    const size_t n = which == 2 ? c->xf_n + 1 : which ? c->xb_n : c->xa_n;
+    c->comm_calls++;
+    if (c->nccl) {
+        ncclResult_t r = rccl().AllReduce(buf, buf, n, ncclUint32, ncclSum, c->nccl, c->stream);
+        if (r != ncclSuccess) return fail(c, ESIM_ENODEVICE, std::string("ncclAllReduce: ") + rccl().GetErrorString(r));
+        return ESIM_OK;
+    }
+    if (c->comm_fn) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->comm_fn(c->comm_user, which, buf, n) != 0) return fail(c, ESIM_ENODEVICE, "the caller's all-reduce failed");
+        return ESIM_OK;
+    }
+    return fail(c, ESIM_ESTATE, "sharded run without a communicator (esim_comm_init_rccl / esim_comm_init_callback)");
+}
+
+}  // namespace
+
+extern "C" int esim_comm_unique_id(void *out, size_t cap)
+{
+    if (!out || cap < sizeof(ncclUniqueId)) return ESIM_EINVAL;
+    if (!rccl().ok) return fail(nullptr, ESIM_ENODEVICE, "librccl could not be loaded");
+    ncclUniqueId id;
+    ncclResult_t r = rccl().GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, ESIM_ENODEVICE, std::string("ncclGetUniqueId: ") + rccl().GetErrorString(r));
+    std::memcpy(out, &id, sizeof id);
+    return ESIM_OK;
+}
+
+extern "C" int esim_comm_init_rccl(esim_ctx *ctx, const void *unique_id, size_t id_bytes, int rank, int world)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !unique_id || id_bytes < sizeof(ncclUniqueId) || rank < 0 || rank >= world) return fail(c, ESIM_EINVAL, "esim_comm_init_rccl: bad argument");
+    if (!rccl().ok) return fail(c, ESIM_ENODEVICE, "librccl could not be loaded");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    if (c->nccl) { rccl().CommDestroy(c->nccl); c->nccl = nullptr; }
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    ncclResult_t r = rccl().CommInitRank(&c->nccl, world, id, rank);
+    if (r != ncclSuccess) { c->nccl = nullptr; return fail(c, ESIM_ENODEVICE, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r)); }
+    c->comm_rank = rank; c->comm_world = world; c->comm_fn = nullptr;
+    return ESIM_OK;
+}
+
+extern "C" int esim_comm_init_callback(esim_ctx *ctx, esim_allreduce_fn fn, void *user, int rank, int world)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !fn || rank < 0 || rank >= world) return fail(c, ESIM_EINVAL, "esim_comm_init_callback: bad argument");
+    if (c->nccl) { rccl().CommDestroy(c->nccl); c->nccl = nullptr; }
+    c->comm_fn = fn; c->comm_user = user; c->comm_rank = rank; c->comm_world = world;
+    return ESIM_OK;
+}
+
+extern "C" int esim_comm_stats(esim_ctx *ctx, uint64_t *collectives)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c) return ESIM_EINVAL;
+    if (collectives) *collectives = c->comm_calls;
+    return ESIM_OK;
+}
+
+// Simulator::simulate's loop for one shard of a sharded population: the protocol of esim_step_begin / _exposures / _finish
+// with the two exchanges, entirely inside the library.  Over RCCL nothing waits for the host: kernels and collectives
+// of all steps are enqueued back to back (a stream synchronisation every 256 steps bounds the queue).
+extern "C" int esim_run_sharded(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_done)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    int rc = check_budget(c, n_steps);
+    if (rc) return rc;
+    if (c->d.n_shards > 1 && !c->nccl && !c->comm_fn) return fail(c, ESIM_ESTATE, "esim_run_sharded: no communicator (esim_comm_init_rccl / esim_comm_init_callback)");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    const uint32_t first = c->host_t;
+    // (a communicator on an unsharded context -- one rank -- still makes its collectives: the sums over one rank change nothing,
+    // which is how the RCCL path is exercised on a one-GPU box)
+    const bool ex = c->d.n_shards > 1 || c->nccl || c->comm_fn;
+    for (uint32_t s = 0; s < n_steps; ++s) {
+        const bool tk = want_kernel_timing(c);
+        if ((rc = enqueue_begin(c, tk))) return rc;
+        if (ex && (rc = exchange(c, 0))) return rc;
+        if ((rc = enqueue_exposures(c, tk))) return rc;
+        if (ex && (rc = exchange(c, 1))) return rc;
+        if ((rc = enqueue_finish(c, tk))) return rc;
+        if ((s & 255u) == 255u) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n_done) *n_done = c->host_t - first;
+    return device_error(c);
 }
 
 extern "C" int esim_future_infected(esim_ctx *ctx)

@@ -49,6 +49,7 @@
 #define FL_BIG_ROUTE      0x20u      // rides a route of more than 64 riders (ranked by a workgroup, not by a wavefront)
 
 #define VACC_BATCH 4096u             // vaccination candidates examined per batch
+#define VACC_WINDOW 32768u           // sharded runs: candidates per step whose liveness the shards exchange (eligible fraction >= rate / window)
 #define VACC_TABLE 16384u            // LDS hash-set slots (>= max rate + VACC_BATCH, power of two)
 #define VACC_MAX_RATE 8192u
 #define NO_ROUTE 0xFFFFFFFFu
@@ -201,7 +202,7 @@ struct Dev {
 // exchange buffer A: [0..4] census, [5] riders, then shared building counts, then shared room counts
 #define XA_HEADER 8u
 // exchange buffer B: [0] building exposures, [1] bus exposures, [2] eligible count, [3] error, then
-// VACC_BATCH/32 words of candidate liveness bits
+// VACC_WINDOW/32 words of candidate liveness bits
 #define XB_HEADER 8u
 // exchange buffer F: Infected census of the next xf_n <= FREE_MAX steps, then one word counting the shards that cannot
 // draw the chunk in one pass

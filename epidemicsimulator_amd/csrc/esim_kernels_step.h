@@ -336,10 +336,12 @@ __global__ __launch_bounds__(TPB) void k_pack_b(Dev d)
         d.xb[2] = trig ? ctrl->n_susceptible - eb - eu : ctrl->elig_count;
         d.xb[3] = ctrl->error;
     }
-    if (i < VACC_BATCH) {
-        const uint32_t j = vacc_candidate(d, i, t);
+    if (i < VACC_WINDOW) {
         bool live = false;
-        if ((ctrl->have_elig || trig) && j >= d.id_base && j - d.id_base < d.n) live = eligible(d.cit[j - d.id_base], tstep);
+        if (ctrl->have_elig || trig) {
+            const uint32_t j = vacc_candidate(d, i, t);
+            if (j >= d.id_base && j - d.id_base < d.n) live = eligible(d.cit[j - d.id_base], tstep);
+        }
         const unsigned long long m = __ballot(live);
         if ((threadIdx.x & 63u) == 0) { d.xb[XB_HEADER + (i >> 5)] = (uint32_t)m; d.xb[XB_HEADER + (i >> 5) + 1] = (uint32_t)(m >> 32); }
     }
@@ -448,7 +450,7 @@ __device__ __forceinline__ void finish_phase(const Dev &d, Ctrl *ctrl, int shard
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t i = base + tid * 4u + q;
                     j[q] = vacc_candidate(d, i, t);
-                    if (sharded) live[q] = (d.xb[XB_HEADER + ((i - base) >> 5)] >> ((i - base) & 31u)) & 1u;
+                    if (sharded) live[q] = i < VACC_WINDOW ? ((d.xb[XB_HEADER + (i >> 5)] >> (i & 31u)) & 1u) != 0u : false;
                     else live[q] = eligible(d.cit[j[q]], tstep);
                     slot[q] = 0;
                     if (live[q]) {
@@ -491,9 +493,9 @@ __device__ __forceinline__ void finish_phase(const Dev &d, Ctrl *ctrl, int shard
                 const uint32_t got = s_total;
                 __syncthreads();
                 already += got < k - already ? got : k - already;
-                // every wave must reach an exit: one batch when sharded (liveness was exchanged for one),
+                // every wave must reach an exit: the window whose liveness was exchanged when sharded,
                 // a hard cap otherwise (an eligible fraction below ~1e-4 would need more candidates)
-                if ((sharded || base >= (1u << 26)) && already < k) { if (tid == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); break; }
+                if (((sharded && base + VACC_BATCH >= VACC_WINDOW) || base >= (1u << 26)) && already < k) { if (tid == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); break; }
             }
             vacc_now = already;
         }

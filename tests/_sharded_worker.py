@@ -22,24 +22,19 @@ def main():
     cfg = json.loads(sys.argv[1])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group(cfg["backend"], rank=rank, world_size=world)
-    pop = Population.synthetic("york", **cfg["spec"])
+    pop = Population.synthetic(cfg.get("preset", "york"), **cfg["spec"])
     ep = _lib.default_params(**cfg["params"])
     dev = int(os.environ.get("LOCAL_RANK", "0"))
-    if rank in cfg.get("tiny_hash_ranks", ()):   # this rank's chunks never fit the one-pass form
-        os.environ["ESIM_HASH_LOG2"] = "4"
-    if cfg.get("cuts") == "even":              # cuts through school catchments: shared buildings, coupled steps
-        sim = ShardedSimulator(pop, rank, world, ep, device_index=dev, cuts=pop.even_cuts(world))
-        assert sim.population.n_shared_buildings > 0 and not sim.mode_free
-    elif cfg.get("cuts") == "generated":       # each rank generates its own shard directly
-        from epidemicsimulator_amd import Population as P
-        sim = ShardedSimulator(None, rank, world, ep, device_index=dev,
-                               shard_population=P.synthetic_shard(rank, world, "york", **cfg["spec"]))
-        assert sim.mode_free
-    else:                                      # commuter-free cuts: decoupled batches until vaccination starts
-        sim = ShardedSimulator(pop, rank, world, ep, device_index=dev)
-        assert sim.population.n_shared_buildings == 0 and sim.mode_free
-    if "burst_max" in cfg and sim.sharded:
-        sim.burst_max = cfg["burst_max"]
+    transport = cfg.get("transport", "callback")   # several ranks on one GPU: the library's exchange goes through gloo
+    if cfg.get("cuts") == "even":                  # cuts through school catchments
+        sim = ShardedSimulator(pop, rank, world, ep, device_index=dev, cuts=pop.even_cuts(world), transport=transport)
+    elif cfg.get("cuts") == "generated":           # esim_synth_create_shard: the world generated and cut inside the library
+        sim = ShardedSimulator(None, rank, world, ep, device_index=dev, transport=transport,
+                               shard_population=Population.synthetic_shard(rank, world, cfg.get("preset", "york"), **cfg["spec"]))
+    else:                                          # the least-crossed cuts near an even split
+        sim = ShardedSimulator(pop, rank, world, ep, device_index=dev, transport=transport)
+    if cfg.get("expect_shared", True) and world > 1:
+        assert sim.population.n_shared_buildings > 0 and sim.population.n_shared_rooms > 0
     orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
     done = 0
     while done < cfg["steps"]:
@@ -60,14 +55,16 @@ def main():
         for k in ("status", "timer", "on_bus", "eligible"):
             assert (st[k] == ost[k][lo:hi]).all(), (rank, k, done)
         done += n
+    if cfg.get("expect"):
+        last = got[-1]
+        for k, v in cfg["expect"].items():
+            assert int(last[k]) >= v, (k, int(last[k]), v)
+    n_coll = sim.collectives()
     dist.barrier()
     sim.close()
     dist.destroy_process_group()
-    if cfg.get("expect_both_modes"):
-        assert sim.free_steps > 0 and sim.coupled_steps > 0, (sim.free_steps, sim.coupled_steps)
-    print("rank %d ok: %d steps (%d decoupled, %d coupled), %d local citizens, %d shared buildings, %d shared rooms"
-          % (rank, cfg["steps"], sim.free_steps, sim.coupled_steps, hi - lo, sim.population.n_shared_buildings,
-             sim.population.n_shared_rooms))
+    print("rank %d ok: %d steps, %d collectives, %d local citizens, %d shared buildings, %d shared rooms"
+          % (rank, cfg["steps"], n_coll, hi - lo, sim.population.n_shared_buildings, sim.population.n_shared_rooms))
 
 
 if __name__ == "__main__":
