@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- citizen-timesteps/sec of the per-timestep Citizen update loop on MI355X.
 
-A "step" is one time step (Simulator::step, sim/src/simulator.rs:131) over the whole synthetic
-population.  Workload: BASELINE.json configs[4], the 64 M-citizen synthetic UK (preset `uk64m`, 10 seeds,
-interventions enabled) -- it fits one GPU, so N=1 runs all of it.  For N>1 the per-GPU work is kept fixed
-(weak scaling): a world of N x 64 M citizens / N x 290 000 Output Areas, Output Areas sharded by whole school
-catchments, one process per GPU; every rank generates only its own shard.  Shards that share no building
-exchange one 96-entry SUM all-reduce per 96 steps (decoupled mode) until a vaccination
-programme starts, then two small all-reduces per step.  Population build and upload are outside the timed
-region; inputs are resident in HBM when it starts.
+A "step" is one time step (Simulator::step, sim/src/simulator.rs:131) over the whole synthetic population.
+Workload: BASELINE.json configs[4], the 64 M-citizen synthetic UK (preset `uk64m`: 10 seeds, interventions on -- the
+lockdown starts around step 3000 and the vaccination programme around step 3240 of its 5000 steps).  It fits one GPU, so
+N = 1 runs all of it.  For N > 1 the SAME world is sharded by Output Areas over the N GPUs (strong scaling, the default):
+every rank builds the world, keeps the band of the map that is its shard (esim_synth_create_shard) and runs
+esim_run_sharded, the library exchanging the commuter counts and the census itself over its own RCCL communicator.
+`--scaling weak` keeps the per-GPU work fixed instead (a world of N x the preset).  Population build and upload are outside
+the timed region; inputs are resident in HBM when it starts.
+
+The timed region is steps 1..K (after W untimed warm-up steps and a reset).  Whatever K is, the line also carries the FULL
+5000-step run of the workload and a run that spends most of its steps under a vaccination programme (`york`, BASELINE.json
+configs[1]), each checked against the records the CPU oracle produced offline (tests/golden/), with wall and device time
+per step -- they cost milliseconds.
 
   python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
          bench.py --gpus N --steps K --warmup W
 """
 import argparse
@@ -23,25 +28,81 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_CITIZEN_STEP = 26.0      # state R+W 4, flags 2, home/work/room ids 12, two count gathers 8
+MODEL_BYTES_PER_CITIZEN_STEP = 26.0     # state R+W 4, flags 2, home/work/room ids 12, two count gathers 8
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+CENSUS = ("susceptible", "exposed", "infected", "recovered", "vaccinated")
 
 
-def cpu_baseline(pop, params, steps, threads):
-    """The CPU oracle (oracle/esim_oracle.c) timed on this host on the first `steps` time steps of the same population, its
-    per-citizen pass on `threads` host threads (the part the reference runs under rayon).  A reported baseline, not the
-    thing measured."""
+def golden_check(preset, rec, seed):
+    """Records of steps 1..len(rec) against the preset's offline oracle run: every record of the first 100 steps, every 50th after."""
+    path = os.path.join(ROOT, "tests", "golden", "oracle_%s_5000.json" % preset)
+    if not os.path.exists(path):
+        return None
+    gold = json.load(open(path))
+    if gold["seed"] != seed:
+        return None
+    compared = 0
+    for want in gold.get("first_records", []) + gold["records"]:
+        t = want["time_step"]
+        if t > len(rec):
+            continue
+        for f in CENSUS:
+            if int(rec[t - 1][f]) != want[f]:
+                raise SystemExit("bench: %s step %d %s = %d, the offline CPU oracle has %d (%s)" % (preset, t, f, int(rec[t - 1][f]), want[f], path))
+        compared += 1
+    return {"file": os.path.relpath(path, ROOT), "records_compared": compared, "match": True}
+
+
+def timed_run(sim, steps):
+    """One esim_run of `steps` steps from time step 0: wall time bracketed by synchronisation, device time of the chunk passes
+    from HIP events on the context's stream (esim_chunk_timing), how the steps were executed."""
+    sim.reset()
+    sim.enable_kernel_timing(16)
+    sim.synchronize()
+    clock = []
+    rec = sim.run(steps, clock=clock)        # esim_run returns with the stream drained and the records on the host
+    wall = clock[0]
+    kc, kv, kp, ks, km = sim.chunk_timing(), sim.vax_chunk_stats(), sim.pipeline_timing(), sim.small_kernel_timing(), sim.kernel_timings()
+    seq_steps = steps - kc["steps"] - kp["steps"]
+    device_ms = kc["chunk_ms"] + kp["steps"] * kp["k_pipe_ms"] + ks["k_small_ms"] + (seq_steps - ks["steps"]) * km["multi_kernel_step_ms"]
+    return rec, {"steps": steps, "wall_us_per_step": wall / steps * 1e6, "device_us_per_step": device_ms / steps * 1e3,
+                 "chunk_steps": kc["steps"], "chunk_passes_device_ms": kc["chunk_ms"], "steps_under_vaccination_in_chunks": kv["steps"],
+                 "chunks_cut": kv["cuts"], "k_pipe_steps": kp["steps"], "sequential_steps": seq_steps,
+                 "steps_with_vaccination_active": int((rec["vaccination_active"] > 0).sum()), "steps_in_lockdown": int((rec["lockdown"] > 0).sum()),
+                 "peak_infected": int(rec["infected"].max()),
+                 "final_record": {k: int(rec[k][-1]) for k in ("time_step",) + CENSUS}}
+
+
+def cpu_baseline(pop, params, seconds, threads):
+    """The reference-shaped CPU path (oracle/esim_refshape.cpp: area-parallel array-of-structs citizens, per-area hash maps,
+    mutex-guarded lookup table -- the structure of sim/src/simulator.rs:87-103,167-260) on this host, on a bounded sample of the
+    workload: the first 1/16 of its Output Areas (a band of the map, cut with esim_shard_population and run as a population of
+    its own), as many steps as fit in about `seconds`.  Returns the figure and (population, records) for the equality check."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
     import _oracle
-    orc = _oracle.Oracle(pop, _oracle.params_from_esim(params))
-    threads = orc.set_threads(threads)
+    cuts = np.asarray([0, max(1, pop.n_areas // 16), pop.n_areas], np.uint32)
+    part = pop.shard(cuts, 0)
+    sample = type(pop)(home_building=part.home_building, work_building=part.work_building, room=part.room, flags=part.flags,
+                       age=part.age, occupation=part.occupation, building_area=part.building_area, building_type=part.building_type,
+                       room_building=part.room_building, seeds=part.seeds if part.n_seeds else np.asarray([0], np.uint32), n_areas=part.n_areas)
     t0 = time.perf_counter()
-    rec = orc.run(steps)
-    dt = time.perf_counter() - t0
-    orc.close()
-    return {"value": pop.n_citizens * len(rec) / dt, "unit": "citizen-timesteps/s", "cores": threads, "kind": "port",
-            "sample": "first %d time steps of the same %d-citizen population, oracle/esim_oracle.c with its per-citizen pass on %d "
-                      "thread(s) (bus sorting, exposures and interventions serial), %.1f s" % (len(rec), pop.n_citizens, threads, dt)}, rec
+    rsh = _oracle.ReferenceShaped(sample, _oracle.params_from_esim(params), threads)
+    build = time.perf_counter() - t0
+    recs, spent, steps = [], 0.0, 0
+    while spent < seconds and steps < 480:
+        t0 = time.perf_counter()
+        recs.append(rsh.run(8))
+        spent += time.perf_counter() - t0
+        steps += 8
+    rsh.close()
+    rec = np.concatenate(recs)
+    return {"value": sample.n_citizens * steps / spent, "unit": "citizen-timesteps/s", "cores": threads, "kind": "reference-shaped",
+            "sample": "Output Areas [0, %d) of the same world (%d citizens, a band of the map cut with esim_shard_population and run as a "
+                      "population of its own), steps 1..%d, oracle/esim_refshape.cpp on %d threads: %.1f s (+ %.1f s to build its structures)"
+                      % (int(cuts[1]), sample.n_citizens, steps, threads, spent, build),
+            "reference_published": "4.36e6 citizen-timesteps/s (3.46 M citizens, 32-core Xeon 6138, rayon 40 threads) and 8.90e6 (York, workstation): "
+                                   "the reference's own runs, different hardware, real census population (BASELINE.md)"}, sample, rec
 
 
 def main():
@@ -50,16 +111,18 @@ def main():
     ap.add_argument("--steps", type=int, default=5000)
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--preset", default="uk64m", help="synthetic population preset (default: the benchmark workload)")
-    ap.add_argument("--cpu-steps", type=int, default=48, help="time steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"), help="N > 1: shard ONE world (strong) or a world N times the preset (weak)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time of the reference-shaped baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = what this process may use, at most 16)")
-    ap.add_argument("--timing-stride", type=int, default=16, help="bracket the per-citizen kernels with HIP events every n-th step")
-    ap.add_argument("--small-limit", type=int, default=None, help="override the persistent-kernel hand-over threshold (Infected citizens)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--transport", default="rccl", choices=("rccl", "callback"), help="N > 1: the library's own RCCL communicator, or its callback transport into torch.distributed (rehearsal on one GPU)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend of the rendezvous (default: nccl for --transport rccl, gloo for callback)")
+    ap.add_argument("--no-extra-runs", action="store_true", help="skip the full-length and vaccination-regime runs")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import torch.distributed as dist
-    from epidemicsimulator_amd import Population, _lib
+    from epidemicsimulator_amd import Population, Simulator, _lib
     from epidemicsimulator_amd.distributed import ShardedSimulator
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -72,137 +135,141 @@ def main():
     if os.environ.get("ESIM_BENCH_SAME_DEVICE"):      # rehearsal of the multi-rank path on a one-GPU box
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-
     steps, warmup = args.steps, min(args.warmup, args.steps)
-    # weak scaling: the world is `world` times the preset, this rank generates its own shard of it
     spec = _lib.SynthSpec()
     _lib.check(_lib.load().esim_synth_preset(args.preset.encode(), __import__("ctypes").byref(spec)))
-    n_total, n_areas = spec.n_citizens * world, spec.n_areas * world
-    pop = Population.synthetic_shard(rank, world, args.preset, n_citizens=n_total, n_areas=n_areas)
-    params = _lib.default_params(max_steps=max(steps, warmup, 1))
-    sim = ShardedSimulator(None, rank, world, params, device_index=local_rank, shard_population=pop)
-    if args.small_limit is not None:
-        sim.set_small_step_limit(args.small_limit)
 
-    def fence():
-        sim.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = args.backend or ("nccl" if args.transport == "rccl" else "gloo")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        mult = world if args.scaling == "weak" else 1
+        n_total, n_areas = spec.n_citizens * mult, spec.n_areas * mult
+        pop = Population.synthetic_shard(rank, world, args.preset, n_citizens=n_total, n_areas=n_areas)
+        params = _lib.default_params(max_steps=max(steps, warmup, 1))
+        sim = ShardedSimulator(None, rank, world, params, device_index=local_rank, shard_population=pop, transport=args.transport)
+
+        def fence():
+            sim.synchronize()
+            torch.cuda.synchronize()
             dist.barrier()
 
-    # W untimed warm-up steps, then back to time step 0 so the timed region is steps 1..K of the workload
-    sim.run(warmup)
-    fence()
-    sim.reset()
-    sim.enable_kernel_timing(args.timing_stride)
-    fence()
-    t0 = time.perf_counter()
-    sim.run(steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
+        sim.run(warmup)
+        fence()
+        sim.reset()
+        fence()
+        t0 = time.perf_counter()
+        sim.run(steps)
+        fence()
+        elapsed = time.perf_counter() - t0
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kt = sim.kernel_timings()
-    ks = sim.small_kernel_timing()
-    kp = sim.pipeline_timing()
-    kc = sim.chunk_timing()
-    rec = sim.records(1, steps)
-
-    if rank == 0:
-        n_local = sim.population.n_citizens
-        value = n_total * steps / elapsed
-        # One time step = one pass of the hot path.  While no vaccination programme runs, steps are processed in
-        # chunks of <= 96 whose inputs are known ahead: normally ALL steps of a chunk are
-        # drawn by one pass of four to six kernels (k_chunk_marks, k_chunk_draw, k_chunk_units, k_chunk_books, and
-        # k_chunk_count / k_chunk_scatter while many are Infected; a burst of chunks is bracketed by one HIP event pair
-        # on the context's stream); when a chunk does not fit that form it runs as one k_pipe launch per step (sampled
-        # event pairs).  Steps that can vaccinate run sequentially:
-        # k_small (persistent, timed per launch) or k_infected + k_expose + k_finish (sampled).  Together they
-        # carry SURVEY.md 8(d)'s 26 algorithmic bytes per citizen-timestep.
-        pipe_steps = kp["steps"]
-        seq_steps = steps - pipe_steps - kc["steps"]
-        big_steps = seq_steps - ks["steps"]
-        parts = {"time-parallel chunk pass (k_chunk_marks, k_chunk_draw, k_chunk_units, k_chunk_books [+ k_chunk_count, "
-                 "k_chunk_scatter while many are Infected])": kc["chunk_ms"],
-                 "k_pipe": pipe_steps * kp["k_pipe_ms"], "k_small": ks["k_small_ms"],
-                 "k_infected+k_expose+k_finish": big_steps * kt["multi_kernel_step_ms"]}
-        step_ms = sum(parts.values()) / steps
-        dom = max(parts, key=parts.get)
-        algo_bytes = ALGO_BYTES_PER_CITIZEN_STEP * n_local
-        achieved = algo_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("workload") == args.preset and tj.get("n_gpus") == world:
-                traffic = tj.get("step_bytes_per_launch")
-        out = {
-            "metric": "citizen-timesteps/sec", "value": value, "unit": "citizen-timesteps/s",
-            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 citizen word, u64 Philox thresholds",
-            "data": "synthetic",
-            "config": {"workload": "%s x %d: %d citizens, %d Output Areas, %d seeds, %d steps, interventions on; "
-                                   "Output Areas sharded by school catchment over %d GPU(s)"
-                                   % (args.preset, world, n_total, n_areas, spec.n_seeds, steps, world),
-                       "citizens_per_gpu": n_local, "seed": int(params.seed),
-                       "decoupled_steps": sim.free_steps, "coupled_steps": sim.coupled_steps},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": dom,
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": step_ms,
-                         "time_parallel_chunks": {"steps": kc["steps"], "chunks": kc["chunks"], "total_ms": kc["chunk_ms"],
-                                                  "ms_per_chunk": kc["chunk_ms"] / kc["chunks"] if kc["chunks"] else None},
-                         "k_pipe": {"steps": kp["steps"], "steps_timed": kp["steps_timed"], "ms_per_launch": kp["k_pipe_ms"]},
-                         "k_small": {"steps": ks["steps"], "total_ms": ks["k_small_ms"],
-                                     "ms_per_step": ks["k_small_ms"] / ks["steps"] if ks["steps"] else None},
-                         "multi_kernel_steps": {"steps": big_steps, "steps_timed": kt["steps_timed"],
-                                                "ms_per_step": kt["multi_kernel_step_ms"]},
-                         "note": "avg_launch_ms = device time of the pass divided by the time steps it covers (a chunk pass "
-                                 "covers up to 96 steps); algorithmic bytes = 26 B x citizens of the shard per time step. "
-                                 "frac >> 1 because the pass never touches most of the model's bytes: only infected citizens "
-                                 "and the members of the buildings they stand in are visited, and the remaining work is "
-                                 "bound by memory latency and kernel boundaries, not by HBM (DESIGN.md sections 3 and 5)",
-                         "wall_algorithmic_GBs": ALGO_BYTES_PER_CITIZEN_STEP * n_total * steps / elapsed / 1e9},
-            "final_record": {k: int(rec[k][-1]) for k in ("time_step", "susceptible", "exposed", "infected", "recovered", "vaccinated")},
-        }
-        if world == 1:
-            # the whole run against records the CPU oracle produced offline for this preset (tests/golden/make_preset_golden.py):
-            # every 50th step up to the steps run here
-            gpath = os.path.join(ROOT, "tests", "golden", "oracle_%s_5000.json" % args.preset)
-            if os.path.exists(gpath):
-                gold = json.load(open(gpath))
-                if gold["seed"] == int(params.seed):
-                    compared = 0
-                    for want in gold["records"]:
-                        if want["time_step"] > steps:
-                            break
-                        got = rec[want["time_step"] - 1]
-                        for f in ("susceptible", "exposed", "infected", "recovered", "vaccinated"):
-                            if int(got[f]) != want[f]:
-                                raise SystemExit("bench: step %d %s = %d, the offline CPU oracle has %d (%s)"
-                                                 % (want["time_step"], f, int(got[f]), want[f], gpath))
-                        compared += 1
-                    out["golden_check"] = {"file": os.path.relpath(gpath, ROOT), "records_compared": compared, "match": True}
-        if world == 1 and args.cpu_steps > 0:
-            n_thr = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))      # the GPU box gives one GPU's job 16 CPUs
-            cb, orc_rec = cpu_baseline(pop, params, min(args.cpu_steps, steps), n_thr)
-            out["cpu_baseline"] = cb
-            for f in ("susceptible", "exposed", "infected", "recovered", "vaccinated"):
-                if not (orc_rec[f] == rec[f][:len(orc_rec)]).all():
-                    raise SystemExit("bench: GPU records differ from the CPU oracle in field %s" % f)
-            out["cpu_baseline"]["records_match_gpu"] = True
-        print(json.dumps(out))
-    sim.close()
-    if world > 1:
+        shared = torch.tensor([pop.n_citizens, pop.n_shared_buildings, pop.n_shared_rooms], dtype=torch.int64, device="cuda")
+        gathered = [torch.zeros_like(shared) for _ in range(world)]
+        dist.all_gather(gathered, shared)
+        rec = sim.records(1, steps)
+        if rank == 0:
+            out = {
+                "metric": "citizen-timesteps/sec", "value": n_total * steps / elapsed, "unit": "citizen-timesteps/s",
+                "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32 citizen word, u64 Philox thresholds",
+                "data": "synthetic",
+                "config": {"workload": "%s%s: %d citizens, %d Output Areas, %d seeds, %d steps, interventions on; Output Areas sharded in bands of the "
+                                       "map over %d GPUs, every step three device phases around two all-reduces the library issues over %s"
+                                       % (args.preset, " x %d" % mult if mult > 1 else "", n_total, n_areas, spec.n_seeds, steps, world,
+                                          "its own RCCL communicator" if args.transport == "rccl" else "its callback transport (%s)" % backend),
+                           "citizens_per_gpu": [int(g[0]) for g in gathered], "shared_buildings": int(gathered[0][1]), "shared_rooms": int(gathered[0][2]),
+                           "collectives": sim.collectives(), "seed": int(params.seed)},
+                "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                             "note": "per-step exchange form: bound by kernel boundaries and collective latency, not by HBM (DESIGN.md 7); the one-GPU line "
+                                     "carries the counter-based figure"},
+                "final_record": {k: int(rec[k][-1]) for k in ("time_step",) + CENSUS},
+            }
+            if args.scaling == "strong":
+                g = golden_check(args.preset, rec, int(params.seed))
+                if g:
+                    out["golden_check"] = g
+            print(json.dumps(out))
+        sim.close()
         dist.destroy_process_group()
+        return
+
+    # ---- one GPU: the whole workload on one context ----------------------------------------------------------------
+    pop = Population.synthetic(args.preset)
+    params = _lib.default_params(max_steps=5000)
+    sim = Simulator(pop, params)
+    sim.run(warmup)                                   # W untimed warm-up steps, then back to time step 0
+    rec, info = timed_run(sim, steps)
+    elapsed = info["wall_us_per_step"] * steps * 1e-6
+    out = {
+        "metric": "citizen-timesteps/sec", "value": pop.n_citizens * steps / elapsed, "unit": "citizen-timesteps/s",
+        "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 citizen word, u64 Philox thresholds", "data": "synthetic",
+        "config": {"workload": "%s: %d citizens, %d Output Areas, %d seeds, steps 1..%d of 5000, interventions on" % (args.preset, pop.n_citizens, pop.n_areas, spec.n_seeds, steps),
+                   "seed": int(params.seed), "timed_region": info},
+        "final_record": info["final_record"],
+    }
+    g = golden_check(args.preset, rec, int(params.seed))
+    if g:
+        out["golden_check"] = g
+    full = info
+    if not args.no_extra_runs:
+        if steps != 5000:
+            rec5, full = timed_run(sim, 5000)
+            full["golden_check"] = golden_check(args.preset, rec5, int(params.seed))
+            full["value"] = pop.n_citizens * 5000 / (full["wall_us_per_step"] * 5000 * 1e-6)
+        out["full_run"] = dict(full, workload="%s, all 5000 steps" % args.preset)
+    # ---- roofline of the dominant work: the time-parallel chunk pass.  HBM bytes per time step come from the PMC passes of the same
+    # workload kept under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md); device time per step is measured here.
+    rf = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+    ppath = os.path.join(ROOT, "profiles", "current_%s.json" % args.preset)
+    if os.path.exists(ppath):
+        prof = json.load(open(ppath))
+        bytes_per_step = prof["hbm_bytes_per_step"]
+        dev_us = full["device_us_per_step"]
+        achieved = bytes_per_step / (dev_us * 1e-6) / 1e9 if dev_us > 0 else 0.0
+        model = MODEL_BYTES_PER_CITIZEN_STEP * pop.n_citizens
+        dom = max(prof["kernels"].items(), key=lambda kv: kv[1]["total_ms"])
+        rf.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": bytes_per_step,
+                   "launch": "one time step of the full 5000-step run (a chunk pass covers up to 96 of them)",
+                   "avg_launch_ms": dev_us * 1e-3, "counters_from": os.path.relpath(ppath, ROOT) + " <- " + prof["tag"],
+                   "model_bytes": model, "traffic_over_model": bytes_per_step / model,
+                   "dominant_kernel": {"name": dom[0], "share_of_device_time": dom[1]["pct"] / 100.0, "avg_us": dom[1]["avg_us"],
+                                       "hbm_bytes_per_launch": dom[1]["hbm_bytes_per_launch"], "achieved_GBs": dom[1]["achieved_GBs"],
+                                       "frac": dom[1]["frac_of_peak"]},
+                   "note": "the pass visits Infected citizens and the members of the buildings they stand in, not all citizens: its HBM traffic is a "
+                           "small fraction of the model's 26 B x citizens per step, and what bounds it is memory latency, Philox arithmetic and "
+                           "kernel boundaries (DESIGN.md 5)"})
+    out["roofline"] = rf
+    if not args.no_extra_runs and args.preset != "york":
+        # a run that spends most of its steps under a vaccination programme: BASELINE.json configs[1]
+        ypop = Population.synthetic("york")
+        ysim = Simulator(ypop, _lib.default_params(max_steps=5000))
+        ysim.run(24)
+        yrec, yinfo = timed_run(ysim, 5000)
+        yinfo["golden_check"] = golden_check("york", yrec, int(params.seed))
+        yinfo["value"] = ypop.n_citizens * 5000 / (yinfo["wall_us_per_step"] * 5000 * 1e-6)
+        out["vaccination_run"] = dict(yinfo, workload="york: %d citizens, 5000 steps, vaccination programme from step %d"
+                                                      % (ypop.n_citizens, int(np.argmax(yrec["vaccination_active"] > 0)) + 1))
+        ysim.close()
+    if args.cpu_seconds > 0:
+        n_thr = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))      # the GPU box gives one GPU's job 16 CPUs
+        cb, sample, cpu_rec = cpu_baseline(pop, params, args.cpu_seconds, n_thr)
+        # the same sample on the GPU: the records must be identical
+        ssim = Simulator(sample, _lib.default_params(max_steps=len(cpu_rec)))
+        srec = ssim.run(len(cpu_rec))
+        ssim.close()
+        for f in CENSUS + ("exposures_building", "exposures_bus"):
+            if not (srec[f] == cpu_rec[f]).all():
+                raise SystemExit("bench: GPU records of the baseline's sample differ from the CPU's in field %s" % f)
+        cb["records_match_gpu"] = True
+        out["cpu_baseline"] = cb
+    print(json.dumps(out))
+    sim.close()
 
 
 if __name__ == "__main__":

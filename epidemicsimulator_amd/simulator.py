@@ -164,16 +164,24 @@ class Simulator:
             DEBUG_ITERATION_PRINT, "%.2f" % (time.time() - start), self.last, _memory_usage()))
 
     # -- device-resident loop ----------------------------------------------------------
-    def run(self, n_steps, stop_when_done=False):
+    def run(self, n_steps, stop_when_done=False, clock=None):
         """`n_steps` of the loop of simulate() without host round trips; returns the records as a
-        structured numpy array (fields of esim_step_result)."""
+        structured numpy array (fields of esim_step_result).  clock: a list that receives the wall seconds of the library
+        call alone (esim_run: enqueue, device work, read-back of the records), without this method's own bookkeeping."""
         buf = (_lib.StepResult * max(1, n_steps))()
         n_done = C.c_uint32(0)
-        _lib.check(self.lib.esim_run(self._ctx, n_steps, int(stop_when_done), buf, C.byref(n_done)), self._ctx)
+        t0 = time.perf_counter()
+        rc = self.lib.esim_run(self._ctx, n_steps, int(stop_when_done), buf, C.byref(n_done))
+        if clock is not None:
+            clock.append(time.perf_counter() - t0)
+        _lib.check(rc, self._ctx)
         self._steps += n_done.value
         arr = np.frombuffer(buf, dtype=RECORD_DTYPE, count=n_done.value).copy()
         self.statistics_recorder.push_block(arr)
         return arr
+
+    def synchronize(self):
+        _lib.check(self.lib.esim_synchronize(self._ctx), self._ctx)
 
     def reset(self):
         _lib.check(self.lib.esim_reset(self._ctx), self._ctx)

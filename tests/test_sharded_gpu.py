@@ -131,3 +131,41 @@ def test_rccl_communicator_of_one_rank():
     for f in ("susceptible", "exposed", "infected", "recovered", "vaccinated", "exposures_building", "exposures_bus", "vaccinated_now"):
         assert (got[f] == want[f]).all(), f
     sim.close()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    # bench.py's N > 1 path end to end (strong scaling: ONE york world sharded over two ranks), the two ranks sharing the test
+    # GPU and the library's exchange going through its callback transport into gloo -- the driver's N-GPU run uses the same loop
+    # over the library's RCCL communicator
+    port = free_port()
+    env = dict(os.environ, ESIM_BENCH_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "900", "--warmup", "24",
+           "--preset", "york", "--transport", "callback"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 900 and d["scaling"] == "strong" and d["value"] > 0
+    assert sum(d["config"]["citizens_per_gpu"]) == 197603 and d["config"]["shared_buildings"] > 0
+    assert d["config"]["collectives"] == 2 * (900 + 24)
+    assert d["golden_check"]["match"] and d["golden_check"]["records_compared"] >= 100 + 18      # first 100 records + every 50th up to 900
+    fr = d["final_record"]
+    assert fr["time_step"] == 900 and fr["vaccinated"] > 0
+    assert fr["susceptible"] + fr["exposed"] + fr["infected"] + fr["recovered"] + fr["vaccinated"] == 197603
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+
+
+def test_bench_one_gpu_line():
+    # the one-GPU line on the york preset: the contract's keys, the golden check of the timed region, the full 5000-step run, a
+    # CPU baseline sample whose records equal the GPU's
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--steps", "20", "--warmup", "5", "--preset", "york", "--cpu-seconds", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["steps"] == 20 and d["golden_check"]["records_compared"] == 20
+    assert d["full_run"]["steps"] == 5000 and d["full_run"]["golden_check"]["records_compared"] == 200
+    assert d["full_run"]["steps_with_vaccination_active"] > 4000 and d["full_run"]["sequential_steps"] < 50
+    assert d["cpu_baseline"]["kind"] == "reference-shaped" and d["cpu_baseline"]["records_match_gpu"]
