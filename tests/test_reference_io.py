@@ -92,3 +92,29 @@ def test_what_the_device_cannot_represent_is_refused():
     areas[1]["citizens"][0]["id"]["global_index"] = areas[1]["citizens"][1]["id"]["global_index"]
     with pytest.raises(ReferenceFormatError, match="repeated"):
         population_from_reference_json(areas)
+
+
+@pytest.mark.gpu
+def test_converted_population_runs_on_the_gpu_like_the_oracle():
+    # a population that arrives in the reference's own serde JSON shape (SimulatorBuilder's output, dumped with
+    # serde_json) is converted and fed to the HIP path; records and per-citizen state equal the oracle's on the same arrays
+    from epidemicsimulator_amd import Simulator
+    src = Population.synthetic("york", n_citizens=9000, n_areas=30, citizens_per_school=3000, n_seeds=15, p_public_transport=0.4)
+    pop, codes = population_from_reference_json(json.loads(json.dumps(population_to_reference_json(src))))
+    assert len(codes) == src.n_areas and pop.n_citizens == src.n_citizens
+    ep = _lib.default_params(exposure_chance=0.004, vaccination_rate=40, vaccination_threshold=0.02, lockdown_threshold=0.03,
+                             mask_pt_threshold=0.005, mask_everywhere_threshold=0.01, seed=5, max_steps=600)
+    sim = Simulator(pop, ep, area_codes=codes)
+    got = sim.run(600)
+    orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
+    want = orc.run(600)
+    for f in ("susceptible", "exposed", "infected", "recovered", "vaccinated", "exposures_building", "exposures_bus", "vaccinated_now", "eligible_count", "lockdown", "mask_status"):
+        assert (got[f] == want[f]).all(), f
+    assert want["vaccinated"][-1] > 0 and want["exposures_bus"].sum() > 0
+    g, o = sim.download_state(), orc.state()
+    for k in ("status", "timer", "current_building", "on_bus", "eligible"):
+        assert (g[k] == o[k]).all(), k
+    # the per-Output-Area exposure series are keyed by the reference's area codes
+    series = sim.exposures_per_output_area(codes)
+    assert set(series) <= set(codes) and sum(sum(v) for v in series.values()) == int(want["exposures_building"].sum())
+    sim.close()
