@@ -179,11 +179,12 @@ def main():
                 "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32 citizen word, u64 Philox thresholds",
                 "data": "synthetic",
                 "config": {"workload": "%s%s: %d citizens, %d Output Areas, %d seeds, %d steps, interventions on; Output Areas sharded in bands of the "
-                                       "map over %d GPUs, every step three device phases around two all-reduces the library issues over %s"
+                                       "map over %d GPUs; time-parallel chunks with one round of exchanges per chunk, coupled steps (two exchanges per step) where a chunk cannot run; the library's exchange goes over %s"
                                        % (args.preset, " x %d" % mult if mult > 1 else "", n_total, n_areas, spec.n_seeds, steps, world,
                                           "its own RCCL communicator" if args.transport == "rccl" else "its callback transport (%s)" % backend),
                            "citizens_per_gpu": [int(g[0]) for g in gathered], "shared_buildings": int(gathered[0][1]), "shared_rooms": int(gathered[0][2]),
-                           "collectives": sim.collectives(), "seed": int(params.seed)},
+                           "collectives": sim.collectives(), "chunk_steps": sim.shard_stats()["chunk_steps"],
+                           "coupled_steps": sim.shard_stats()["coupled_steps"], "seed": int(params.seed)},
                 "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                              "note": "per-step exchange form: bound by kernel boundaries and collective latency, not by HBM (DESIGN.md 7); the one-GPU line "
                                      "carries the counter-based figure"},

@@ -58,6 +58,9 @@ struct esim_ctx_impl {
     int comm_rank = 0, comm_world = 1;
     ncclComm_t nccl = nullptr;
     esim_allreduce_fn comm_fn = nullptr; void *comm_user = nullptr;
+    std::vector<uint32_t> comm_stage;
+    uint32_t *xr = nullptr; size_t xr_n = 0;      // records exchange (sharded chunks)
+    uint64_t shard_chunk_steps = 0, shard_step_steps = 0;
     uint64_t comm_calls = 0;
     std::vector<hipEvent_t> fev; size_t fev_used = 0;                               // chunks of an open decoupled burst
     std::vector<hipEvent_t> pkev; size_t pkev_used = 0; uint64_t pipe_steps = 0;   // sampled k_pipe launches
@@ -438,6 +441,19 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     d.n_shared_bld = pop->n_shared_buildings; d.n_shared_room = pop->n_shared_rooms;
     if ((rc = dev_upload(c, &d.shared_bld, pop->shared_building_local, pop->n_shared_buildings))) return rc;
     if ((rc = dev_upload(c, &d.shared_room, pop->shared_room_local, pop->n_shared_rooms))) return rc;
+    {
+        // the inverse of the shared tables: which shared slot a local building / room is (sharded chunks, k_shared_pack)
+        std::vector<int32_t> of_b(B ? B : 1, -1), of_r(R ? R : 1, -1);
+        for (uint32_t i = 0; i < pop->n_shared_buildings; ++i) if (pop->shared_building_local[i] >= 0) of_b[pop->shared_building_local[i]] = (int32_t)i;
+        for (uint32_t i = 0; i < pop->n_shared_rooms; ++i) if (pop->shared_room_local[i] >= 0) of_r[pop->shared_room_local[i]] = (int32_t)i;
+        if ((rc = dev_upload(c, &d.shared_of_bld, of_b.data(), of_b.size()))) return rc;
+        if ((rc = dev_upload(c, &d.shared_of_room, of_r.data(), of_r.size()))) return rc;
+        if ((rc = dev_alloc(c, &d.xv, XV_HEADER + (size_t)FREE_MAX * (PLAN_W / 32u)))) return rc;
+        if ((rc = dev_alloc(c, &d.xc, FREE_MAX + 2u))) return rc;
+        HIP_TRY(c, hipMemset(d.xv, 0, sizeof(uint32_t) * (XV_HEADER + (size_t)FREE_MAX * (PLAN_W / 32u))));
+        HIP_TRY(c, hipMemset(d.xc, 0, sizeof(uint32_t) * (FREE_MAX + 2u)));
+        d.rank = 0; d.world = 1; d.xs = nullptr;
+    }
 #ifdef ESIM_WAVE_PROFILE
     if ((rc = dev_alloc(c, &d.prof_buf, (size_t)16384 * 16))) return rc;
     HIP_TRY(c, hipMemset(d.prof_buf, 0, sizeof(uint32_t) * 16384 * 16));
@@ -567,6 +583,11 @@ bool want_kernel_timing(esim_ctx_impl *c)
     return true;
 }
 
+int fail_dev(esim_ctx_impl *c, uint32_t err)
+{
+    return fail(c, -(int)err, "device-side error (S underflow / vaccination window exhausted / a chunk table overflowed)");
+}
+
 int device_error(esim_ctx_impl *c)
 {
     Ctrl h;
@@ -674,9 +695,9 @@ void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
 {
     Dev &d = c->d;
     hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
-    hipLaunchKernelGGL(k_chunk_vax, dim3(FREE_MAX), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+    hipLaunchKernelGGL(k_chunk_vax, dim3(FREE_MAX), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 0);
     hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 0);
     hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
@@ -692,7 +713,7 @@ void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
 int run_chunk(esim_ctx_impl *c, uint32_t n_ahead, uint32_t *executed, Ctrl *state_before)
 {
     Dev &d = c->d;
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, n_ahead, c->P.max_steps, c->time_parallel ? 1 : 0);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, n_ahead, c->P.max_steps, c->time_parallel ? 1 : 0, 0);
     Ctrl h;
     HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -793,7 +814,7 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             const bool tk = c->kernel_timing;
             if (tk) { if (!c->cev[0]) { (void)hipEventCreate(&c->cev[0]); (void)hipEventCreate(&c->cev[1]); } HIP_TRY(c, hipEventRecord(c->cev[0], c->stream)); }
             hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
-            hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1);
+            hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 0);
             for (uint32_t g = 0; g < bursts; ++g) enqueue_parallel_chunk(c, g + 1u < bursts ? 1 : 0, limit_t);
             if (tk) HIP_TRY(c, hipEventRecord(c->cev[1], c->stream));
             Ctrl h;
@@ -901,6 +922,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -918,8 +940,9 @@ RcclApi &rccl()
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
     api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
+    api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
-    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.GetErrorString;
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.AllGather && api.GetErrorString;
     return api;
 }
 
@@ -929,12 +952,10 @@ void comm_release(esim_ctx_impl *c)
     c->nccl = nullptr;
 }
 
-// SUM all-reduce of exchange buffer `which` (0 A, 1 B, 2 F) over the shards, in place, ordered after everything enqueued so far.
-int exchange(esim_ctx_impl *c, int which)
+// SUM all-reduce of n uint32 at device pointer buf over the shards, in place, ordered after everything enqueued so far.
+// `which` names the buffer for a caller's transport (0 A, 1 B, 2 F, 3 plan liveness, 4 commuter records, 5 cuts, 6 records).
+int exchange_buf(esim_ctx_impl *c, int which, uint32_t *buf, size_t n)
 {
-    Dev &d = c->d;
-    uint32_t *buf = which == 2 ? d.xf : which ? d.xb : d.xa;
-    const size_t n = which == 2 ? c->xf_n + 1 : which ? c->xb_n : c->xa_n;
     c->comm_calls++;
     if (c->nccl) {
         ncclResult_t r = rccl().AllReduce(buf, buf, n, ncclUint32, ncclSum, c->nccl, c->stream);
@@ -942,11 +963,51 @@ int exchange(esim_ctx_impl *c, int which)
         return ESIM_OK;
     }
     if (c->comm_fn) {
+        // the caller's transport works on host memory: stage through a host buffer with the stream drained
+        c->comm_stage.resize(n);
+        HIP_TRY(c, hipMemcpyAsync(c->comm_stage.data(), buf, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->comm_fn(c->comm_user, which, buf, n) != 0) return fail(c, ESIM_ENODEVICE, "the caller's all-reduce failed");
+        if (c->comm_fn(c->comm_user, which, c->comm_stage.data(), n) != 0) return fail(c, ESIM_ENODEVICE, "the caller's all-reduce failed");
+        HIP_TRY(c, hipMemcpyAsync(buf, c->comm_stage.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
         return ESIM_OK;
     }
     return fail(c, ESIM_ESTATE, "sharded run without a communicator (esim_comm_init_rccl / esim_comm_init_callback)");
+}
+
+// All-gather: every rank contributes the `per_rank` words at buf + rank * per_rank and receives everybody's.  Over a caller's
+// transport: a SUM all-reduce of the whole buffer, the other ranks' segments zeroed first (k_zero_segments).
+int exchange_gather(esim_ctx_impl *c, int which, uint32_t *buf, size_t per_rank)
+{
+    if (c->nccl) {
+        c->comm_calls++;
+        ncclResult_t r = rccl().AllGather(buf + (size_t)c->comm_rank * per_rank, buf, per_rank, ncclUint32, c->nccl, c->stream);
+        if (r != ncclSuccess) return fail(c, ESIM_ENODEVICE, std::string("ncclAllGather: ") + rccl().GetErrorString(r));
+        return ESIM_OK;
+    }
+    return exchange_buf(c, which, buf, per_rank * (size_t)c->comm_world);
+}
+
+// what the exchange of sharded chunks needs once the number of ranks is known
+int comm_buffers(esim_ctx_impl *c)
+{
+    if (!c->uploaded) return fail(c, ESIM_ESTATE, "esim_comm_init: upload the population first");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    Dev &d = c->d;
+    d.rank = (uint32_t)c->comm_rank; d.world = (uint32_t)c->comm_world;
+    const size_t n = (size_t)d.world * (1u + 3u * XS_CAP);
+    int rc;
+    if ((rc = dev_alloc(c, &d.xs, n))) return rc;
+    HIP_TRY(c, hipMemset(d.xs, 0, sizeof(uint32_t) * n));
+    return ESIM_OK;
+}
+
+int exchange(esim_ctx_impl *c, int which)
+{
+    Dev &d = c->d;
+    uint32_t *buf = which == 2 ? d.xf : which ? d.xb : d.xa;
+    const size_t n = which == 2 ? c->xf_n + 1 : which ? c->xb_n : c->xa_n;
+    return exchange_buf(c, which, buf, n);
 }
 
 }  // namespace
@@ -974,7 +1035,7 @@ extern "C" int esim_comm_init_rccl(esim_ctx *ctx, const void *unique_id, size_t 
     ncclResult_t r = rccl().CommInitRank(&c->nccl, world, id, rank);
     if (r != ncclSuccess) { c->nccl = nullptr; return fail(c, ESIM_ENODEVICE, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r)); }
     c->comm_rank = rank; c->comm_world = world; c->comm_fn = nullptr;
-    return ESIM_OK;
+    return comm_buffers(c);
 }
 
 extern "C" int esim_comm_init_callback(esim_ctx *ctx, esim_allreduce_fn fn, void *user, int rank, int world)
@@ -983,7 +1044,7 @@ extern "C" int esim_comm_init_callback(esim_ctx *ctx, esim_allreduce_fn fn, void
     if (!c || !fn || rank < 0 || rank >= world) return fail(c, ESIM_EINVAL, "esim_comm_init_callback: bad argument");
     if (c->nccl) { rccl().CommDestroy(c->nccl); c->nccl = nullptr; }
     c->comm_fn = fn; c->comm_user = user; c->comm_rank = rank; c->comm_world = world;
-    return ESIM_OK;
+    return comm_buffers(c);
 }
 
 extern "C" int esim_comm_stats(esim_ctx *ctx, uint64_t *collectives)
@@ -994,21 +1055,48 @@ extern "C" int esim_comm_stats(esim_ctx *ctx, uint64_t *collectives)
     return ESIM_OK;
 }
 
-// Simulator::simulate's loop for one shard of a sharded population: the protocol of esim_step_begin / _exposures / _finish
-// with the two exchanges, entirely inside the library.  Over RCCL nothing waits for the host: kernels and collectives
-// of all steps are enqueued back to back (a stream synchronisation every 256 steps bounds the queue).
-extern "C" int esim_run_sharded(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_done)
+namespace {
+
+// One time-parallel chunk of a sharded run: what the shards exchange once per chunk instead of once per step --
+// the liveness of the plan's candidates (V), the Infected commuters to shared buildings (S, all-gathered), the Infected census
+// ahead with the "cannot" word (F), the steps with a cut (C).  Kernels and collectives are enqueued on the context's stream.
+int enqueue_sharded_chunk(esim_ctx_impl *c, uint32_t limit_t, bool vax)
 {
-    esim_ctx_impl *c = CTX(ctx);
-    int rc = check_budget(c, n_steps);
-    if (rc) return rc;
-    if (c->d.n_shards > 1 && !c->nccl && !c->comm_fn) return fail(c, ESIM_ESTATE, "esim_run_sharded: no communicator (esim_comm_init_rccl / esim_comm_init_callback)");
-    HIP_TRY(c, hipSetDevice(c->P.device));
-    const uint32_t first = c->host_t;
-    // (a communicator on an unsharded context -- one rank -- still makes its collectives: the sums over one rank change nothing,
-    // which is how the RCCL path is exercised on a one-GPU box)
-    const bool ex = c->d.n_shards > 1 || c->nccl || c->comm_fn;
-    for (uint32_t s = 0; s < n_steps; ++s) {
+    Dev &d = c->d;
+    int rc;
+    hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+    if (vax) {
+        hipLaunchKernelGGL(k_vax_live, dim3(PLAN_W / TPB, FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+        if ((rc = exchange_buf(c, 3, d.xv, XV_HEADER + (size_t)FREE_MAX * (PLAN_W / 32u)))) return rc;
+        hipLaunchKernelGGL(k_chunk_vax, dim3(FREE_MAX), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1);
+        hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+    }
+    const size_t seg = 1u + 3u * (size_t)XS_CAP;
+    HIP_TRY(c, hipMemsetAsync(d.xs + (size_t)d.rank * seg, 0, sizeof(uint32_t), c->stream));
+    if (c->comm_fn)          // (a caller's transport sums the whole buffer: the other ranks' segments must be zero)
+        for (uint32_t r = 0; r < d.world; ++r) if (r != d.rank) HIP_TRY(c, hipMemsetAsync(d.xs + (size_t)r * seg, 0, sizeof(uint32_t) * seg, c->stream));
+    hipLaunchKernelGGL(k_shared_pack, dim3(256), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+    if ((rc = exchange_gather(c, 4, d.xs, seg))) return rc;
+    hipLaunchKernelGGL(k_shard_prep, dim3(1), dim3(128), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+    if ((rc = exchange(c, 2))) return rc;
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 1);
+    hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);
+    if (vax && (rc = exchange_buf(c, 5, d.xc, FREE_MAX + 2u))) return rc;
+    hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, 0, 0, (uint32_t)c->xf_n, limit_t);
+    hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_vax_final, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d);
+    HIP_TRY(c, hipGetLastError());
+    return ESIM_OK;
+}
+
+// n coupled steps: three device phases around the two per-step exchanges (the form every step can take)
+int run_coupled_steps(esim_ctx_impl *c, uint32_t n, bool ex)
+{
+    int rc;
+    for (uint32_t s = 0; s < n; ++s) {
         const bool tk = want_kernel_timing(c);
         if ((rc = enqueue_begin(c, tk))) return rc;
         if (ex && (rc = exchange(c, 0))) return rc;
@@ -1017,9 +1105,76 @@ extern "C" int esim_run_sharded(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_don
         if ((rc = enqueue_finish(c, tk))) return rc;
         if ((s & 255u) == 255u) HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    c->shard_step_steps += n;
+    return ESIM_OK;
+}
+
+}  // namespace
+
+// Simulator::simulate's loop for one shard of a sharded population.  Steps run as time-parallel chunks with one round of
+// exchanges per chunk wherever a chunk can run on every shard, and as coupled steps (three device phases around two exchanges
+// per step) otherwise: the step that starts the vaccination programme, chunks that do not fit the one-pass form somewhere, plans
+// that need more candidates than the exchanged window.  Every rank takes the same decisions from the same reduced words.
+// Over RCCL nothing waits for the host inside a burst of chunks.
+extern "C" int esim_run_sharded(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_done)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    int rc = check_budget(c, n_steps);
+    if (rc) return rc;
+    if (c->d.n_shards > 1 && !c->nccl && !c->comm_fn) return fail(c, ESIM_ESTATE, "esim_run_sharded: no communicator (esim_comm_init_rccl / esim_comm_init_callback)");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    Dev &d = c->d;
+    const uint32_t first = c->host_t;
+    // (a communicator on an unsharded context -- one rank -- still makes its collectives: the sums over one rank change nothing,
+    // which is how the RCCL path is exercised on a one-GPU box)
+    const bool ex = d.n_shards > 1 || c->nccl || c->comm_fn;
+    const bool chunks = ex && d.xs && c->pipeline && c->time_parallel && d.items_cap > 0;
+    std::vector<std::pair<uint32_t, uint32_t>> local_ranges;     // [first step, count) whose records hold this shard's census
+    uint32_t remaining = n_steps, stall = 0;
+    while (remaining > 0) {
+        if (chunks && (!c->elig_seen || c->vax_chunks)) {
+            const uint32_t t_first = c->host_t, limit_t = t_first + remaining - 1u;
+            const uint32_t bursts = stall ? 1u : std::min<uint32_t>((remaining + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n + (c->elig_seen ? 1u : 0u), 4u);
+            for (uint32_t g = 0; g < bursts; ++g) if ((rc = enqueue_sharded_chunk(c, limit_t, c->elig_seen))) return rc;
+            Ctrl h;
+            HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (h.error) return fail_dev(c, h.error);
+            const uint32_t done = h.t - t_first;
+            c->host_t = h.t; remaining -= done;
+            c->shard_chunk_steps += done;
+            if (done) { local_ranges.emplace_back(t_first, done); stall = 0; continue; }
+            stall = std::min<uint32_t>(stall + 1u, 8u);
+        }
+        const uint32_t k = std::min<uint32_t>(remaining, (!chunks || (c->elig_seen && !c->vax_chunks)) ? remaining : (stall <= 1u ? 1u : (stall <= 3u ? 8u : (uint32_t)c->xf_n)));
+        if ((rc = run_coupled_steps(c, k, ex))) return rc;
+        remaining -= k;
+        Ctrl h;
+        HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (h.error) return fail_dev(c, h.error);
+        c->elig_seen = h.have_elig != 0u;
+    }
+    // the records of the steps drawn as chunks: this shard's census -> everybody's
+    for (auto &rg : local_ranges) {
+        const size_t n = (size_t)rg.second * XR_FIELDS;
+        if (n > c->xr_n) { if ((rc = dev_alloc(c, &c->xr, n))) return rc; c->xr_n = n; }
+        hipLaunchKernelGGL(k_records_pack, dim3(grid_for(rg.second, TPB, 64)), dim3(TPB), 0, c->stream, d, rg.first, rg.second, c->xr);
+        if (ex && (rc = exchange_buf(c, 6, c->xr, n))) return rc;
+        hipLaunchKernelGGL(k_records_unpack, dim3(grid_for(rg.second, TPB, 64)), dim3(TPB), 0, c->stream, d, rg.first, rg.second, c->xr);
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (n_done) *n_done = c->host_t - first;
     return device_error(c);
+}
+
+extern "C" int esim_shard_stats(esim_ctx *ctx, uint64_t *chunk_steps, uint64_t *coupled_steps)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c) return ESIM_EINVAL;
+    if (chunk_steps) *chunk_steps = c->shard_chunk_steps;
+    if (coupled_steps) *coupled_steps = c->shard_step_steps;
+    return ESIM_OK;
 }
 
 extern "C" int esim_future_infected(esim_ctx *ctx)
@@ -1056,7 +1211,7 @@ extern "C" int esim_free_enqueue(esim_ctx *ctx)
     if (tk && c->fev_used + 2 > c->fev.size())
         for (int i = 0; i < 2 && tk; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) tk = false; else c->fev.push_back(e); }
     if (tk) HIP_TRY(c, hipEventRecord(c->fev[c->fev_used], c->stream));
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d, (uint32_t)c->xf_n, c->free_limit, 1);
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d, (uint32_t)c->xf_n, c->free_limit, 1, 0);
     enqueue_parallel_chunk(c, 2, c->free_limit);                  // leaves the census ahead of the NEXT chunk in buffer F
     if (tk) { HIP_TRY(c, hipEventRecord(c->fev[c->fev_used + 1], c->stream)); c->fev_used += 2; }
     HIP_TRY(c, hipGetLastError());

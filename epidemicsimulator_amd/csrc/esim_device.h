@@ -102,6 +102,7 @@ struct Ctrl {
     uint32_t prev_n, prev_n_eff, prev_vax; // the chunk k_chunk_scatter is finishing: its length, the steps committed, whether it was planned
     uint32_t vax_cuts;          // diagnostics: chunks that were cut short
     uint32_t vax_planned, prev_planned; // steps the plan of the chunk in preparation / being finished covers (>= the chunk's length)
+    uint32_t vax_fail;          // sharded plans: steps whose candidates beyond the exchanged window would have been needed (plan void)
 };
 
 // A deferred unit of a long member list: UNIT_PAIRS (member, marked step) pairs from pair p_lo on.  code = kind << 30 | p_lo
@@ -192,6 +193,12 @@ struct Dev {
     uint32_t n_shared_bld, n_shared_room;
     const int32_t *shared_bld, *shared_room;
     uint32_t *xa, *xb, *xf;             // exchange buffers A, B and the future-infected vector
+    // sharded time-parallel chunks: what the shards exchange once per chunk
+    uint32_t rank, world;
+    uint32_t *xv;                       // [XV_HEADER + FREE_MAX * PLAN_W / 32] liveness of every step's first PLAN_W vaccination candidates
+    uint32_t *xs;                       // [world][1 + 3 * XS_CAP] Infected commuters to shared buildings: (citizen word, shared building, shared room | -1)
+    uint32_t *xc;                       // [FREE_MAX + 2] steps of the chunk with a cut (k_chunk_count), error flag
+    const int32_t *shared_of_bld, *shared_of_room;   // [n_bld], [n_room]: index into the shared tables, -1 when not shared
 #ifdef ESIM_WAVE_PROFILE
     uint32_t *prof_buf;                 // diagnostics build only: [wavefronts][16] timers of the last chunk (tools/wave_profile.py)
 #endif
@@ -208,6 +215,9 @@ struct Dev {
 // draw the chunk in one pass
 #define FREE_MAX 96u
 #define HKEY_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define PLAN_W 4096u               // sharded plans: candidates per step whose liveness is exchanged (one batch)
+#define XV_HEADER 8u               // [0] eligible count, [1] riders, [2] shards that cannot plan -- summed over the shards
+#define XS_CAP 32768u              // commuter records a shard can send per chunk
 // Shared lists of the chunk pass are split so that no single address takes more than a few atomics per pass (atomics on
 // one address are served one at a time, ~10 ns each): every counter has a 128-byte line of its own in Dev::hot.
 #define HOT_STRIDE 32u             // uint32 per counter

@@ -71,7 +71,7 @@ __device__ __forceinline__ uint32_t mask_compose(uint32_t g, uint32_t f)
     return ((g >> (2u * (f & 3u))) & 3u) | (((g >> (2u * ((f >> 2) & 3u))) & 3u) << 2) | (((g >> (2u * ((f >> 4) & 3u))) & 3u) << 4);
 }
 
-__device__ __forceinline__ void decide_body(const Dev &d, uint32_t max_ahead, uint32_t limit_t, int allow_parallel)
+__device__ __forceinline__ void decide_body(const Dev &d, uint32_t max_ahead, uint32_t limit_t, int allow_parallel, int adj_folded = 0)
 {
     // One wavefront, no serial loop.  Lane l evaluates the (strict) threshold tests of steps l and 64 + l
     // (interventions.rs:116-170).  Then, per step j of the chunk:
@@ -88,9 +88,9 @@ __device__ __forceinline__ void decide_body(const Dev &d, uint32_t max_ahead, ui
     // under a vaccination programme only a chunk whose vaccinations are planned may run (k_chunk_vax); the Infected census ahead
     // then loses those the plan vaccinates before (prefix sums of xf_adj)
     const bool vax = ld(&ctrl->have_elig) != 0u;
-    const bool ok = (vax ? (ld(&ctrl->vax_chunk) != 0u) : !ld(&ctrl->vacc_active)) && !ld(&ctrl->need_seq) && !ld(&ctrl->finished) && !ld(&ctrl->error) && ld(&ctrl->free_base) == t0;
+    const bool ok = (vax ? (ld(&ctrl->vax_chunk) != 0u && ld(&ctrl->vax_fail) == 0u) : !ld(&ctrl->vacc_active)) && !ld(&ctrl->need_seq) && !ld(&ctrl->finished) && !ld(&ctrl->error) && ld(&ctrl->free_base) == t0;
     uint32_t adj[2] = { 0u, 0u };
-    if (vax && ok) {
+    if (vax && ok && !adj_folded) {                       // (sharded: folded into buffer F before its all-reduce, k_shard_prep)
         uint32_t carry = 0u;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -229,9 +229,9 @@ __device__ __forceinline__ void decide_body(const Dev &d, uint32_t max_ahead, ui
     if (lane < FREE_MAX - 64u) d.cursor[64u + lane] = 0u;
 }
 
-__global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32_t limit_t, int allow_parallel)
+__global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32_t limit_t, int allow_parallel, int adj_folded)
 {
-    decide_body(d, max_ahead, limit_t, allow_parallel);
+    decide_body(d, max_ahead, limit_t, allow_parallel, adj_folded);
 }
 
 // ------------------------------------------------------------------ vaccination inside a chunk
@@ -249,41 +249,73 @@ __global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32
 // committed up to s* - 1 and the next chunk starts AT s*.  What happens in step s* itself does not depend on the plan from s*
 // on, so everybody the cut chunk saw exposed on a bus in s* will be again: k_chunk_scatter marks them (CW_PLAN_SKIP) and the
 // next plan leaves them out -- it cannot be cut at s* again.
-__global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead, uint32_t limit_t)
+// Sharded runs: a candidate's eligibility is known to the shard that owns the citizen.  k_vax_live writes, for every step of
+// the chunk ahead, the liveness bits of its first PLAN_W candidates (own citizens only; the shards SUM-all-reduce buffer V, the
+// bits being disjoint) and, in the header, this shard's eligible count, riders and whether it can plan at all.
+__global__ __launch_bounds__(TPB) void k_vax_live(Dev d, uint32_t max_ahead, uint32_t limit_t)
+{
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t j = blockIdx.y, i = blockIdx.x * TPB + threadIdx.x;
+    const uint32_t t0 = ctrl->t;
+    const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
+    if (j == 0 && blockIdx.x == 0 && threadIdx.x < XV_HEADER) {
+        const uint32_t k = threadIdx.x;
+        d.xv[k] = k == 0 ? ctrl->elig_count : k == 1 ? d.n_pt : k == 2 ? ((ctrl->finished || ctrl->error) ? 1u : 0u) : 0u;
+        if (k == 0) ctrl->vax_fail = 0u;
+    }
+    bool live = false;
+    if (ctrl->have_elig && j < n_ahead) {
+        const uint32_t cand = vacc_candidate(d, i, t0 + j);
+        if (cand >= d.id_base && cand - d.id_base < d.n) { const uint32_t w = d.cit[cand - d.id_base]; live = eligible(w, ctrl->trigger_step) && !(w & CW_PLAN_SKIP); }
+    }
+    const unsigned long long m = __ballot(live);
+    if ((threadIdx.x & 63u) == 0) { uint32_t *row = d.xv + XV_HEADER + (size_t)j * (PLAN_W / 32u); row[i >> 5] = (uint32_t)m; row[(i >> 5) + 1u] = (uint32_t)(m >> 32); }
+}
+
+// sharded: the liveness of the candidates comes from buffer V (k_vax_live, all-reduced), every shard walks the same sequence
+// and accepts the same candidates, and keeps the events of its own citizens.
+__global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead, uint32_t limit_t, int sharded)
 {
     __shared__ FinishShared sm;
+    __shared__ uint32_t n_local;
     Ctrl *ctrl = d.ctrl;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t j = blockIdx.x;
     const uint32_t t0 = ctrl->t;
     const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
-    // (every workgroup takes the same decision from the same words; nothing here writes them)
-    const bool plan = ctrl->have_elig && !ctrl->finished && !ctrl->error && !ctrl->need_seq && d.n_shards == 1u &&
-                      ctrl->elig_count > d.vaccination_rate + d.n_pt;      // the set cannot shrink to the "whole set" case inside the chunk
+    // (every workgroup -- and, sharded, every shard -- takes the same decision from the same words; nothing here writes them)
+    const uint32_t elig_all = sharded ? d.xv[0] : ctrl->elig_count, riders_all = sharded ? d.xv[1] : d.n_pt;
+    const bool plan = ctrl->have_elig && !ctrl->finished && !ctrl->error && !ctrl->need_seq && !(sharded && d.xv[2]) &&
+                      elig_all > d.vaccination_rate + riders_all;      // the set cannot shrink to the "whole set" case inside the chunk
     if (tid == 0) {
         d.xf_adj[j] = 0u;
         for (uint32_t q = 0; q < 4u; ++q) d.vax_delta[q * (FREE_MAX + 2u) + j] = 0u;
         d.vax_cnt[j] = 0u; d.vax_now[j] = 0u;
+        n_local = 0u;
         if (j == 0) {
             ctrl->vax_chunk = plan ? 1u : 0u;
             ctrl->vax_planned = plan ? n_ahead : 0u;
+            if (!sharded) ctrl->vax_fail = 0u;
             ctrl->chunk_cut = FREE_MAX + 1u;
             for (uint32_t z = FREE_MAX; z < FREE_MAX + 2u; ++z) { d.xf_adj[z] = 0u; for (uint32_t q = 0; q < 4u; ++q) d.vax_delta[q * (FREE_MAX + 2u) + z] = 0u; }
         }
     }
     if (!plan || j >= n_ahead) return;
     const uint32_t t = t0 + j, k = d.vaccination_rate, tstep = ctrl->trigger_step;
+    const uint32_t *bits = d.xv + XV_HEADER + (size_t)j * (PLAN_W / 32u);
     for (uint32_t i = tid; i < VACC_TABLE; i += FIN_TPB) { sm.tab_key[i] = 0xFFFFFFFFu; sm.tab_idx[i] = 0xFFFFFFFFu; }
     __syncthreads();
     uint32_t already = 0;
     for (uint32_t base = 0; already < k; base += VACC_BATCH) {
-        uint32_t cj[4], slot[4], cw[4]; bool live[4];
+        uint32_t cj[4], slot[4], cw[4]; bool live[4], mine_c[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t i = base + tid * 4u + q;
             cj[q] = vacc_candidate(d, i, t);
-            cw[q] = d.cit[cj[q]];
-            live[q] = eligible(cw[q], tstep) && !(cw[q] & CW_PLAN_SKIP);
+            mine_c[q] = cj[q] >= d.id_base && cj[q] - d.id_base < d.n;
+            cw[q] = mine_c[q] ? d.cit[cj[q] - d.id_base] : 0u;
+            if (sharded) live[q] = i < PLAN_W && ((bits[i >> 5] >> (i & 31u)) & 1u) != 0u;
+            else live[q] = eligible(cw[q], tstep) && !(cw[q] & CW_PLAN_SKIP);
             slot[q] = 0;
             if (live[q]) {
                 uint32_t sl = (cj[q] * 2654435761u) >> 18;        // 14 bits
@@ -311,10 +343,11 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (first[q]) {
-                if (pos < k) {
-                    d.vax_ev[(size_t)j * VACC_MAX_RATE + pos] = cj[q];
+                if (pos < k && mine_c[q]) {
+                    const uint32_t c = cj[q] - d.id_base;
+                    d.vax_ev[(size_t)j * VACC_MAX_RATE + atomicAdd(&n_local, 1u)] = c;      // (the order inside a step does not matter)
                     // unconditional (simulator.rs:551) -- but a citizen that is Vaccinated already stays what it is
-                    if (CW_TE(cw[q]) != TE_VACCINATED) atomicMax(&d.cit[cj[q]], (cw[q] & ~CW_VAX_MASK) | CW_VAX_FIELD(j));
+                    if (CW_TE(cw[q]) != TE_VACCINATED) atomicMax(&d.cit[c], (cw[q] & ~CW_VAX_MASK) | CW_VAX_FIELD(j));
                 }
                 pos++;
             }
@@ -322,9 +355,11 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead
         const uint32_t got = sm.s_total;
         __syncthreads();
         already += got < k - already ? got : k - already;
+        if (sharded && base + VACC_BATCH >= PLAN_W && already < k) { if (tid == 0) atomicAdd(&ctrl->vax_fail, 1u); break; }   // the window was too short: no plan
         if (base >= (1u << 26) && already < k) { if (tid == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); break; }   // every wave must reach an exit
     }
-    if (tid == 0) { d.vax_cnt[j] = already; d.vax_now[j] = already; }
+    __syncthreads();
+    if (tid == 0) { d.vax_cnt[j] = n_local; d.vax_now[j] = already; }
 }
 
 // The Infected census ahead (buffer F) counts everybody whose exposure step makes it Infected; those the plan vaccinates
@@ -333,7 +368,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead
 __global__ __launch_bounds__(TPB) void k_chunk_vax_adj(Dev d, uint32_t max_ahead, uint32_t limit_t)
 {
     const Ctrl *ctrl = d.ctrl;
-    if (!ctrl->vax_chunk) return;
+    if (!ctrl->vax_chunk || ctrl->vax_fail) return;
     const uint32_t t0 = ctrl->t;
     const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
     const uint32_t j = blockIdx.x;
@@ -346,6 +381,74 @@ __global__ __launch_bounds__(TPB) void k_chunk_vax_adj(Dev d, uint32_t max_ahead
         const int lo = a > (int)j + 1 ? a : (int)j + 1, hi = min(a + (int)d.infected_time, (int)n_ahead - 1);
         if (lo <= hi) { atomicSub(&d.xf_adj[lo], 1u); atomicAdd(&d.xf_adj[hi + 1], 1u); }
     }
+}
+
+// ---------------------------------------------------------------------- sharded chunks: the commuter exchange
+// A building or school room whose members live on several shards is shared (esim_shard_population).  An Infected member
+// standing in it matters to every shard that has members there: per chunk, each shard sends the citizen words of its own
+// Infected whose work building is shared, with the building's and the room's index in the shared tables (k_shared_pack; the
+// segments are all-gathered), and k_chunk_marks enters the received ones into its map next to its own.  The slice walked is
+// the one of the longest chunk that can follow (the decisions come later); an entry whose stretch misses the chunk is dropped
+// by the receiver.
+__global__ __launch_bounds__(TPB) void k_shared_pack(Dev d, uint32_t max_ahead, uint32_t limit_t)
+{
+    const Ctrl *ctrl = d.ctrl;
+    uint32_t *seg = d.xs + (size_t)d.rank * (1u + 3u * XS_CAP);
+    const uint32_t t0 = ctrl->t;
+    const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
+    if (n_ahead == 0u) return;
+    const int lo_te = (int)(t0 + TE_BIAS) - (int)d.exposed_time - 1 - (int)d.infected_time;
+    const int hi_te = (int)(t0 + n_ahead + TE_BIAS) - (int)d.exposed_time - 2;
+    if (hi_te < 0) return;
+    const uint32_t i0 = d.log_off[lo_te < 0 ? 0 : lo_te], i1 = d.log_off[hi_te + 1];
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base = i0 + (blockIdx.x * TPB + threadIdx.x - lane); base < i1; base += gridDim.x * TPB) {
+        const uint32_t i = base + lane;
+        uint32_t w = 0u, sb = 0u, sr = 0xFFFFFFFFu;
+        bool send = false;
+        if (i < i1) {
+            const uint32_t c = d.log[i];
+            w = d.cit[c];
+            if ((w & FL_HAS_WORK) && CW_TE(w) < TE_RECOVERED) {
+                const int32_t k = d.shared_of_bld[d.work[c]];
+                if (k >= 0) {
+                    send = true; sb = (uint32_t)k;
+                    if (w & FL_WORK_SCHOOL) { const int32_t q = d.shared_of_room[d.room[c]]; sr = q >= 0 ? (uint32_t)q : 0xFFFFFFFFu; }
+                }
+            }
+        }
+        const unsigned long long m = __ballot(send);
+        if (!m) continue;
+        uint32_t pos = 0u;
+        if (lane == 0) pos = atomicAdd(&seg[0], (uint32_t)__popcll(m));       // one atomic per wavefront
+        pos = __shfl(pos, 0, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (send && pos < XS_CAP) { seg[1u + 3u * pos] = w; seg[2u + 3u * pos] = sb; seg[3u + 3u * pos] = sr; }
+    }
+}
+
+// Before buffer F is all-reduced: this shard's "cannot draw the chunk in one pass" word also covers the commuters received (they
+// claim items too) and a segment that overflowed anywhere; and the Infected census ahead loses those the plan vaccinates before
+// (prefix sums of xf_adj), so that the sum over the shards is the census the decisions need.
+__global__ __launch_bounds__(128) void k_shard_prep(Dev d, uint32_t max_ahead, uint32_t limit_t)
+{
+    Ctrl *ctrl = d.ctrl;
+    if (threadIdx.x != 0) return;
+    const uint32_t t0 = ctrl->t;
+    const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
+    uint32_t n_remote = 0u; bool overflow = false;
+    for (uint32_t r = 0; r < d.world; ++r) {
+        const uint32_t cnt = d.xs[(size_t)r * (1u + 3u * XS_CAP)];
+        if (cnt > XS_CAP) overflow = true;
+        if (r != d.rank) n_remote += min(cnt, XS_CAP);
+    }
+    const bool fits = d.xf[d.xf_n] == 0u && !overflow &&
+                      ((unsigned long long)ctrl->chunk_pairs + n_remote) * 4ull + 65536ull <= (unsigned long long)d.items_cap;
+    d.xf[d.xf_n] = fits ? 0u : 1u;
+    if (ctrl->vax_chunk && !ctrl->vax_fail) {
+        uint32_t a = 0u;
+        for (uint32_t j = 0; j < n_ahead; ++j) { a += d.xf_adj[j]; d.xf[j] += a; }
+    }
+    for (uint32_t j = 0; j < FREE_MAX + 2u; ++j) d.xc[j] = 0u;
 }
 
 // Marks of the first step of a chunk (the later ones are made by the k_pipe of the step before).
@@ -444,7 +547,9 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
     const uint32_t i0 = ctrl->chunk_i0, i1 = ctrl->chunk_i1;                 // log slice of the chunk's Infected (k_decide)
     // every wavefront owns a fixed range of item ids (a citizen claims at most four items), so no counter is shared
-    const uint32_t per_wave = 4u * ((i1 - i0 + n_waves - 1u) / n_waves);
+    uint32_t n_remote = 0u;
+    if (d.world > 1u) for (uint32_t r = 0; r < d.world; ++r) if (r != d.rank) n_remote += min(d.xs[(size_t)r * (1u + 3u * XS_CAP)], XS_CAP);
+    const uint32_t per_wave = 4u * ((i1 - i0 + n_remote + n_waves - 1u) / n_waves + (n_remote ? 1u : 0u));
     if (wave == 0 && lane == 0) { ctrl->items_per_wave = per_wave; ctrl->n_items = per_wave * n_waves; }
     if ((unsigned long long)per_wave * n_waves > d.items_cap) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); return; }
     uint32_t next_id = wave * per_wave;
@@ -466,15 +571,13 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
     uint32_t ps[5] = { 0u, 0u, 0u, 0u, 0u };                                   // diagnostics: time per stage
     uint32_t ps_alu = 0u;
     const uint32_t pm_loop = PROF_NOW();
-    for (uint32_t e = i0 + wave; e < i1; e += n_waves) {
-        const uint32_t w = w_n, ksrc = k_n;
-        const uint32_t pa = PROF_NOW();
-        if (e + n_waves < i1) { c_n = d.log[e + n_waves]; w_n = d.cit[c_n]; if (lane < 4u) k_n = key_src[c_n]; }
+    auto process = [&](const uint32_t w, const uint32_t ksrc, const bool remote, const uint32_t pa) {
         const uint32_t p0 = lane < n ? where_in_step(d, w, t0, lane, q0) : 0u;
         const uint32_t p1 = 64u + lane < n ? where_in_step(d, w, t0, 64u + lane, q1) : 0u;
-        const bool any_home = __any((p0 | p1) & 1u), any_work = __any((p0 | p1) & 2u), any_bus = __any((p0 | p1) & 4u);
+        // (a commuter from another shard only counts where it works: its home and its route are its own shard's business)
+        const bool any_home = !remote && __any((p0 | p1) & 1u), any_work = __any((p0 | p1) & 2u), any_bus = !remote && __any((p0 | p1) & 4u);
         const bool school = w & FL_WORK_SCHOOL;
-        if (!any_home && !any_work && !any_bus) continue;
+        if (!any_home && !any_work && !any_bus) return;
         ++p_entries;
         const uint32_t pb = PROF_NOW();
         // the citizen is Infected in steps [a, b] of the chunk (one stretch: disease.rs:60-65); where it stands in each of
@@ -487,7 +590,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         unsigned long long key = HKEY_EMPTY;
         if (lane == 0 && any_home) key = ksrc;
         if (lane == 1 && any_work) key = ksrc;
-        if (lane == 2 && any_work && school) key = (unsigned long long)d.n_bld + ksrc;
+        if (lane == 2 && any_work && school && ksrc != 0xFFFFFFFFu) key = (unsigned long long)d.n_bld + ksrc;   // (a remote commuter's room may have no member here)
         if (lane == 3 && any_bus) key = (unsigned long long)d.n_bld + d.n_room + ksrc;
         uint32_t slot = 0u;
         bool pending = false, claimed = false;
@@ -577,6 +680,30 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
             }
         }
         { const uint32_t pf = PROF_NOW(); ps[0] += pb - pa; ps[1] += pc - pb; ps[2] += pd - pc; ps[3] += pe - pd; ps[4] += pf - pe; }
+    };
+    for (uint32_t e = i0 + wave; e < i1; e += n_waves) {
+        const uint32_t w = w_n, ksrc = k_n;
+        const uint32_t pa = PROF_NOW();
+        if (e + n_waves < i1) { c_n = d.log[e + n_waves]; w_n = d.cit[c_n]; if (lane < 4u) k_n = key_src[c_n]; }
+        process(w, ksrc, false, pa);
+    }
+    // Sharded: the Infected commuters the other shards sent (k_shared_pack, all-gathered): each stands in a building (and room)
+    // that has members here too; it enters the map like a local citizen's work building and room.
+    if (d.world > 1u) {
+        uint32_t seen = 0u;                                                   // remote entries before this shard's segment
+        for (uint32_t r = 0; r < d.world; ++r) {
+            if (r == d.rank) continue;
+            const uint32_t *seg = d.xs + (size_t)r * (1u + 3u * XS_CAP);
+            const uint32_t cnt = min(seg[0], XS_CAP);
+            for (uint32_t e = (wave + n_waves - seen % n_waves) % n_waves; e < cnt; e += n_waves) {
+                const uint32_t w = seg[1u + 3u * e], sb = seg[2u + 3u * e], sr = seg[3u + 3u * e];
+                const int32_t lb = d.shared_bld[sb];
+                if (lb < 0) continue;                                         // nobody of that building lives here
+                const int32_t lr = sr != 0xFFFFFFFFu ? d.shared_room[sr] : -1;
+                process(w, lane == 1u ? (uint32_t)lb : lane == 2u ? (lr >= 0 ? (uint32_t)lr : 0xFFFFFFFFu) : 0u, true, PROF_NOW());
+            }
+            seen += cnt;
+        }
     }
     if (lane == 0) { d.pair_cnt[wave] = my_pairs; d.used_cnt[wave] = next_id - wave * per_wave; }
     const uint32_t pm1 = PROF_NOW();
@@ -1051,7 +1178,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_count(Dev d)
         const uint32_t s = CW_TE(w) - TE_BIAS;
         atomicAdd(&d.exp_step[2u * s + ((w & CW_BUS_EXPOSED) ? 1u : 0u)], 1u);
         // exposed on a bus although the plan vaccinates it later in the chunk: from this step on the plan is void (k_chunk_vax)
-        if ((w & CW_BUS_EXPOSED) && CW_VAX_REL(w) != CW_VAX_NONE) atomicMin(&ctrl->chunk_cut, s - t0);
+        if ((w & CW_BUS_EXPOSED) && CW_VAX_REL(w) != CW_VAX_NONE) { atomicMin(&ctrl->chunk_cut, s - t0); if (d.world > 1u) d.xc[s - t0] = 1u; }
     }
     if (!ctrl->vax_chunk) return;
     // What the chunk's vaccinations do to the census of its later steps, from the words as the draws left them: one thread per
@@ -1169,7 +1296,11 @@ __device__ __forceinline__ uint32_t batch_finish_body(const Dev &d, uint32_t t0,
     const uint32_t tid = threadIdx.x;
     const int et = (int)d.exposed_time, it = (int)d.infected_time;
     const int base_idx = (int)(t0 + TE_BIAS) - et - 1 - it;              // lowest histogram entry any census of the chunk reads
-    const uint32_t n_cut = vax ? min(n, ld(&ctrl->chunk_cut)) : n;
+    uint32_t n_cut = vax ? min(n, ld(&ctrl->chunk_cut)) : n;
+    if (vax && d.world > 1u) {                                            // sharded: the earliest cut of any shard (buffer C, summed)
+        n_cut = n;
+        for (uint32_t j = 0; j < n; ++j) if (ld(&d.xc[j])) { n_cut = j; break; }
+    }
     // H[i] = citizens exposed in "step" base_idx + i: the histogram before the chunk, this chunk's exposure counters inside it
     {
         const int k = base_idx + (int)tid;

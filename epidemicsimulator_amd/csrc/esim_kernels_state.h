@@ -30,3 +30,28 @@ __global__ __launch_bounds__(TPB) void k_decode_state(Dev d, uint8_t *status, ui
     }
 }
 
+
+// Sharded runs: steps drawn as chunks hold this shard's census; the additive fields of records [first, first + n) are summed
+// over the shards (buffer R) and written back, disease_exists follows.
+#define XR_FIELDS 9u
+__global__ __launch_bounds__(TPB) void k_records_pack(Dev d, uint32_t first, uint32_t n, uint32_t *xr)
+{
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+        const esim_step_result r = d.records[first + i];
+        uint32_t *o = xr + (size_t)i * XR_FIELDS;
+        o[0] = r.susceptible; o[1] = r.exposed; o[2] = r.infected; o[3] = r.recovered; o[4] = r.vaccinated;
+        o[5] = r.exposures_building; o[6] = r.exposures_bus; o[7] = r.n_riders; o[8] = r.eligible_count;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_records_unpack(Dev d, uint32_t first, uint32_t n, const uint32_t *xr)
+{
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+        esim_step_result r = d.records[first + i];
+        const uint32_t *o = xr + (size_t)i * XR_FIELDS;
+        r.susceptible = o[0]; r.exposed = o[1]; r.infected = o[2]; r.recovered = o[3]; r.vaccinated = o[4];
+        r.exposures_building = o[5]; r.exposures_bus = o[6]; r.n_riders = o[7]; r.eligible_count = o[8];
+        r.disease_exists = (r.exposed != 0u || r.infected != 0u || r.susceptible != 0u) ? 1u : 0u;
+        d.records[first + i] = r;
+    }
+}

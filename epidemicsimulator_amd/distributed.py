@@ -84,20 +84,10 @@ class ShardedSimulator:
             buf = (C.c_uint8 * 128).from_buffer_copy(box[0])
             _lib.check(self.lib.esim_comm_init_rccl(self._ctx, buf, 128, rank, world_size), self._ctx)
         elif self.sharded:
-            # exchange buffers the collective library can address: torch tensors registered with the context
-            self.xbuf = []
-            for which in (0, 1, 2):
-                n = C.c_size_t(0)
-                ptr = C.c_void_p()
-                _lib.check(self.lib.esim_exchange_buffer(self._ctx, which, C.byref(ptr), C.byref(n)), self._ctx)
-                t = torch.zeros(max(1, n.value), dtype=torch.int32, device="cuda:%d" % device_index)
-                _lib.check(self.lib.esim_set_exchange_buffer(self._ctx, which, C.c_void_p(t.data_ptr())), self._ctx)
-                self.xbuf.append(t)
-
-            def allreduce(_user, which, _ptr, _n):
+            def allreduce(_user, _which, host_ptr, n):
                 try:
-                    dist.all_reduce(self.xbuf[which], group=self.group)
-                    torch.cuda.synchronize()
+                    a = np.ctypeslib.as_array(C.cast(host_ptr, C.POINTER(C.c_int32)), shape=(n,))
+                    dist.all_reduce(torch.from_numpy(a), group=self.group)      # in place, on the library's staging buffer
                     return 0
                 except Exception:          # never unwind into the library
                     return 1
@@ -132,6 +122,12 @@ class ShardedSimulator:
         n = C.c_uint64(0)
         _lib.check(self.lib.esim_comm_stats(self._ctx, C.byref(n)), self._ctx)
         return n.value
+
+    def shard_stats(self):
+        """Steps run as time-parallel chunks (one round of exchanges per chunk) / as coupled steps (two exchanges per step)."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(self.lib.esim_shard_stats(self._ctx, C.byref(a), C.byref(b)), self._ctx)
+        return {"chunk_steps": a.value, "coupled_steps": b.value}
 
     def reset(self):
         _lib.check(self.lib.esim_reset(self._ctx), self._ctx)

@@ -174,18 +174,22 @@ int  esim_exchange_buffer(esim_ctx *ctx, int which /* 0 = A, 1 = B, 2 = F */, vo
  *                            (the Rust caller over whatever it launches its processes with; bench.py over torch.distributed)
  * esim_comm_init_rccl     -- collective over all ranks: an RCCL communicator on the context's device; every exchange is then
  *                            an ncclAllReduce enqueued on the context's stream between its kernels
- * esim_comm_init_callback -- instead: the caller's own SUM all-reduce (in place, `n_u32` uint32 at `device_ptr`, which = 0 A,
- *                            1 B, 2 F), called with the stream drained; returns 0 on success.  For transports other than RCCL
- *                            and for tests that put several ranks on one GPU.
+ * esim_comm_init_callback -- instead: the caller's own SUM all-reduce over the ranks, in place, of `n_u32` uint32 in HOST memory
+ *                            at `host_ptr` (the library stages the device buffer through it with the stream drained; `which`
+ *                            names the buffer: 0 A, 1 B, 2 F, 3 plan liveness, 4 commuter records, 5 cuts, 6 records);
+ *                            returns 0 on success.  For transports other than RCCL and for tests with several ranks on one GPU.
  * esim_run_sharded        -- replaces the loop of Simulator::simulate (simulator.rs:114-123) for this rank's shard: n_steps
  *                            time steps, every rank calling it with the same n_steps; records of these steps hold the census
  *                            of the WHOLE population on every rank. */
-typedef int (*esim_allreduce_fn)(void *user, int which, void *device_ptr, size_t n_u32);
+typedef int (*esim_allreduce_fn)(void *user, int which, void *host_ptr, size_t n_u32);
 int  esim_comm_unique_id(void *out, size_t cap);
 int  esim_comm_init_rccl(esim_ctx *ctx, const void *unique_id, size_t id_bytes, int rank, int world);
 int  esim_comm_init_callback(esim_ctx *ctx, esim_allreduce_fn fn, void *user, int rank, int world);
 int  esim_comm_stats(esim_ctx *ctx, uint64_t *collectives);
 int  esim_run_sharded(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_done);
+/* How the steps of sharded runs were executed so far: as time-parallel chunks (one round of exchanges per chunk) / as coupled
+ * steps (two exchanges per step). */
+int  esim_shard_stats(esim_ctx *ctx, uint64_t *chunk_steps, uint64_t *coupled_steps);
 int  esim_future_infected(esim_ctx *ctx);
 int  esim_run_free(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_done);
 int  esim_free_begin(esim_ctx *ctx, uint32_t n_steps);

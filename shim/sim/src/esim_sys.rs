@@ -84,7 +84,7 @@ pub struct EsimStepResult {
 }
 
 /// esim_allreduce_fn: a caller-supplied SUM all-reduce for transports other than RCCL
-pub type EsimAllreduceFn = extern "C" fn(user: *mut c_void, which: c_int, device_ptr: *mut c_void, n_u32: usize) -> c_int;
+pub type EsimAllreduceFn = extern "C" fn(user: *mut c_void, which: c_int, host_ptr: *mut c_void, n_u32: usize) -> c_int;
 
 #[link(name = "esim")]
 extern "C" {

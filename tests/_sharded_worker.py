@@ -35,6 +35,8 @@ def main():
         sim = ShardedSimulator(pop, rank, world, ep, device_index=dev, transport=transport)
     if cfg.get("expect_shared", True) and world > 1:
         assert sim.population.n_shared_buildings > 0 and sim.population.n_shared_rooms > 0
+    if cfg.get("pipeline") is not None:
+        sim.set_pipeline(cfg["pipeline"])          # 0: coupled steps only
     orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
     done = 0
     while done < cfg["steps"]:
@@ -60,11 +62,14 @@ def main():
         for k, v in cfg["expect"].items():
             assert int(last[k]) >= v, (k, int(last[k]), v)
     n_coll = sim.collectives()
+    st = sim.shard_stats()
+    if cfg.get("pipeline") is None and world > 1:
+        assert st["chunk_steps"] > 0, st                      # the default form draws chunks wherever it can
     dist.barrier()
     sim.close()
     dist.destroy_process_group()
-    print("rank %d ok: %d steps, %d collectives, %d local citizens, %d shared buildings, %d shared rooms"
-          % (rank, cfg["steps"], n_coll, hi - lo, sim.population.n_shared_buildings, sim.population.n_shared_rooms))
+    print("rank %d ok: %d steps (%d in chunks, %d coupled), %d collectives, %d local citizens, %d shared buildings, %d shared rooms"
+          % (rank, cfg["steps"], st["chunk_steps"], st["coupled_steps"], n_coll, hi - lo, sim.population.n_shared_buildings, sim.population.n_shared_rooms))
 
 
 if __name__ == "__main__":
