@@ -995,7 +995,8 @@ int comm_buffers(esim_ctx_impl *c)
     HIP_TRY(c, hipSetDevice(c->P.device));
     Dev &d = c->d;
     d.rank = (uint32_t)c->comm_rank; d.world = (uint32_t)c->comm_world;
-    const size_t n = (size_t)d.world * (1u + 3u * XS_CAP);
+    const size_t n = (size_t)d.world * (1u + 3u * (size_t)XS_CAP_MAX);
+    d.xs_cap = 4096u;
     int rc;
     if ((rc = dev_alloc(c, &d.xs, n))) return rc;
     HIP_TRY(c, hipMemset(d.xs, 0, sizeof(uint32_t) * n));
@@ -1071,7 +1072,7 @@ int enqueue_sharded_chunk(esim_ctx_impl *c, uint32_t limit_t, bool vax)
         hipLaunchKernelGGL(k_chunk_vax, dim3(FREE_MAX), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1);
         hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
     }
-    const size_t seg = 1u + 3u * (size_t)XS_CAP;
+    const size_t seg = 1u + 3u * (size_t)d.xs_cap;
     HIP_TRY(c, hipMemsetAsync(d.xs + (size_t)d.rank * seg, 0, sizeof(uint32_t), c->stream));
     if (c->comm_fn)          // (a caller's transport sums the whole buffer: the other ranks' segments must be zero)
         for (uint32_t r = 0; r < d.world; ++r) if (r != d.rank) HIP_TRY(c, hipMemsetAsync(d.xs + (size_t)r * seg, 0, sizeof(uint32_t) * seg, c->stream));
@@ -1143,7 +1144,14 @@ extern "C" int esim_run_sharded(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_don
             const uint32_t done = h.t - t_first;
             c->host_t = h.t; remaining -= done;
             c->shard_chunk_steps += done;
+            // the commuter segment follows the need (the same on every rank: the counts were gathered)
+            const uint32_t cap_before = d.xs_cap;
+            while (d.xs_cap < XS_CAP_MAX && 2u * h.xs_need > d.xs_cap) d.xs_cap *= 2u;
             if (done) { local_ranges.emplace_back(t_first, done); stall = 0; continue; }
+            if (std::getenv("ESIM_DEBUG"))
+                std::fprintf(stderr, "[esim] rank %d: sharded chunk without progress at t=%u: chunk_ok=%u parallel=%u vax_chunk=%u vax_fail=%u cannot=%u xs_need=%u xs_cap=%u pairs=%u\n",
+                             c->comm_rank, h.t, h.chunk_ok, h.chunk_parallel, h.vax_chunk, h.vax_fail, 0u, h.xs_need, cap_before, h.chunk_pairs);
+            if (d.xs_cap != cap_before) continue;                        // the segment was too short: again with the longer one
             stall = std::min<uint32_t>(stall + 1u, 8u);
         }
         const uint32_t k = std::min<uint32_t>(remaining, (!chunks || (c->elig_seen && !c->vax_chunks)) ? remaining : (stall <= 1u ? 1u : (stall <= 3u ? 8u : (uint32_t)c->xf_n)));

@@ -102,6 +102,7 @@ struct Ctrl {
     uint32_t prev_n, prev_n_eff, prev_vax; // the chunk k_chunk_scatter is finishing: its length, the steps committed, whether it was planned
     uint32_t vax_cuts;          // diagnostics: chunks that were cut short
     uint32_t vax_planned, prev_planned; // steps the plan of the chunk in preparation / being finished covers (>= the chunk's length)
+    uint32_t xs_need;           // sharded chunks: the most commuter records any shard wanted to send for the chunk last prepared
     uint32_t vax_fail;          // sharded plans: steps whose candidates beyond the exchanged window would have been needed (plan void)
 };
 
@@ -196,7 +197,8 @@ struct Dev {
     // sharded time-parallel chunks: what the shards exchange once per chunk
     uint32_t rank, world;
     uint32_t *xv;                       // [XV_HEADER + FREE_MAX * PLAN_W / 32] liveness of every step's first PLAN_W vaccination candidates
-    uint32_t *xs;                       // [world][1 + 3 * XS_CAP] Infected commuters to shared buildings: (citizen word, shared building, shared room | -1)
+    uint32_t *xs;                       // [world][1 + 3 * xs_cap] Infected commuters to shared buildings: (citizen word, shared building, shared room | -1)
+    uint32_t xs_cap;                    // records per shard in this chunk's exchange
     uint32_t *xc;                       // [FREE_MAX + 2] steps of the chunk with a cut (k_chunk_count), error flag
     const int32_t *shared_of_bld, *shared_of_room;   // [n_bld], [n_room]: index into the shared tables, -1 when not shared
 #ifdef ESIM_WAVE_PROFILE
@@ -217,7 +219,7 @@ struct Dev {
 #define HKEY_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define PLAN_W 4096u               // sharded plans: candidates per step whose liveness is exchanged (one batch)
 #define XV_HEADER 8u               // [0] eligible count, [1] riders, [2] shards that cannot plan -- summed over the shards
-#define XS_CAP 32768u              // commuter records a shard can send per chunk
+#define XS_CAP_MAX (1u << 20)      // commuter records a shard can send per chunk at most (the segment in use, Dev::xs_cap, grows with the need)
 // Shared lists of the chunk pass are split so that no single address takes more than a few atomics per pass (atomics on
 // one address are served one at a time, ~10 ns each): every counter has a 128-byte line of its own in Dev::hot.
 #define HOT_STRIDE 32u             // uint32 per counter

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_vax_adj(Dev d, uint32_t max_ahead
 __global__ __launch_bounds__(TPB) void k_shared_pack(Dev d, uint32_t max_ahead, uint32_t limit_t)
 {
     const Ctrl *ctrl = d.ctrl;
-    uint32_t *seg = d.xs + (size_t)d.rank * (1u + 3u * XS_CAP);
+    uint32_t *seg = d.xs + (size_t)d.rank * (1u + 3u * d.xs_cap);
     const uint32_t t0 = ctrl->t;
     const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
     if (n_ahead == 0u) return;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(TPB) void k_shared_pack(Dev d, uint32_t max_ahead, 
         uint32_t pos = 0u;
         if (lane == 0) pos = atomicAdd(&seg[0], (uint32_t)__popcll(m));       // one atomic per wavefront
         pos = __shfl(pos, 0, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (send && pos < XS_CAP) { seg[1u + 3u * pos] = w; seg[2u + 3u * pos] = sb; seg[3u + 3u * pos] = sr; }
+        if (send && pos < d.xs_cap) { seg[1u + 3u * pos] = w; seg[2u + 3u * pos] = sb; seg[3u + 3u * pos] = sr; }
     }
 }
 
@@ -437,10 +437,12 @@ __global__ __launch_bounds__(128) void k_shard_prep(Dev d, uint32_t max_ahead, u
     const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
     uint32_t n_remote = 0u; bool overflow = false;
     for (uint32_t r = 0; r < d.world; ++r) {
-        const uint32_t cnt = d.xs[(size_t)r * (1u + 3u * XS_CAP)];
-        if (cnt > XS_CAP) overflow = true;
-        if (r != d.rank) n_remote += min(cnt, XS_CAP);
+        const uint32_t cnt = d.xs[(size_t)r * (1u + 3u * d.xs_cap)];
+        if (cnt > d.xs_cap) overflow = true;
+        if (r != d.rank) n_remote += min(cnt, d.xs_cap);
     }
+    ctrl->xs_need = 0u;
+    for (uint32_t r = 0; r < d.world; ++r) ctrl->xs_need = max(ctrl->xs_need, d.xs[(size_t)r * (1u + 3u * d.xs_cap)]);
     const bool fits = d.xf[d.xf_n] == 0u && !overflow &&
                       ((unsigned long long)ctrl->chunk_pairs + n_remote) * 4ull + 65536ull <= (unsigned long long)d.items_cap;
     d.xf[d.xf_n] = fits ? 0u : 1u;
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
     const uint32_t i0 = ctrl->chunk_i0, i1 = ctrl->chunk_i1;                 // log slice of the chunk's Infected (k_decide)
     // every wavefront owns a fixed range of item ids (a citizen claims at most four items), so no counter is shared
     uint32_t n_remote = 0u;
-    if (d.world > 1u) for (uint32_t r = 0; r < d.world; ++r) if (r != d.rank) n_remote += min(d.xs[(size_t)r * (1u + 3u * XS_CAP)], XS_CAP);
+    if (d.world > 1u) for (uint32_t r = 0; r < d.world; ++r) if (r != d.rank) n_remote += min(d.xs[(size_t)r * (1u + 3u * d.xs_cap)], d.xs_cap);
     const uint32_t per_wave = 4u * ((i1 - i0 + n_remote + n_waves - 1u) / n_waves + (n_remote ? 1u : 0u));
     if (wave == 0 && lane == 0) { ctrl->items_per_wave = per_wave; ctrl->n_items = per_wave * n_waves; }
     if ((unsigned long long)per_wave * n_waves > d.items_cap) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); return; }
@@ -693,8 +695,8 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         uint32_t seen = 0u;                                                   // remote entries before this shard's segment
         for (uint32_t r = 0; r < d.world; ++r) {
             if (r == d.rank) continue;
-            const uint32_t *seg = d.xs + (size_t)r * (1u + 3u * XS_CAP);
-            const uint32_t cnt = min(seg[0], XS_CAP);
+            const uint32_t *seg = d.xs + (size_t)r * (1u + 3u * d.xs_cap);
+            const uint32_t cnt = min(seg[0], d.xs_cap);
             for (uint32_t e = (wave + n_waves - seen % n_waves) % n_waves; e < cnt; e += n_waves) {
                 const uint32_t w = seg[1u + 3u * e], sb = seg[2u + 3u * e], sr = seg[3u + 3u * e];
                 const int32_t lb = d.shared_bld[sb];
