@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time of the reference-shaped baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = what this process may use, at most 16)")
     ap.add_argument("--transport", default="rccl", choices=("rccl", "callback"), help="N > 1: the library's own RCCL communicator, or its callback transport into torch.distributed (rehearsal on one GPU)")
-    ap.add_argument("--backend", default=None, help="torch.distributed backend of the rendezvous (default: nccl for --transport rccl, gloo for callback)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend of the rendezvous (default gloo: it only carries the unique id, barriers and the timing maximum)")
     ap.add_argument("--no-extra-runs", action="store_true", help="skip the full-length and vaccination-regime runs")
     args = ap.parse_args()
 
@@ -141,7 +141,7 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = args.backend or ("nccl" if args.transport == "rccl" else "gloo")
+        backend = args.backend or "gloo"          # the rendezvous only carries the RCCL unique id, the barriers and the timing maximum
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -165,10 +165,11 @@ def main():
         sim.run(steps)
         fence()
         elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        shared = torch.tensor([pop.n_citizens, pop.n_shared_buildings, pop.n_shared_rooms], dtype=torch.int64, device="cuda")
+        shared = torch.tensor([pop.n_citizens, pop.n_shared_buildings, pop.n_shared_rooms], dtype=torch.int64, device=dev)
         gathered = [torch.zeros_like(shared) for _ in range(world)]
         dist.all_gather(gathered, shared)
         rec = sim.records(1, steps)

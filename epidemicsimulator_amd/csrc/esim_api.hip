@@ -934,7 +934,9 @@ RcclApi &rccl()
     if (tried) return api;
     tried = true;
     void *h = nullptr;
-    for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    // a copy the process has loaded already (e.g. the one PyTorch ships) is reused: one RCCL runtime per process
+    for (const char *name : { "librccl.so", "librccl.so.1" }) if ((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!h) for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
     if (!h) return api;
     api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
