@@ -735,19 +735,21 @@ struct RouteShared {
     uint8_t s_inf[CHUNK_ROUTE_MAX];
     uint32_t s_cnt[CHUNK_ROUTE_MAX + 1];
 };
-struct WaveScratch { uint32_t cnt[FREE_MAX]; uint32_t sch[FREE_MAX]; uint32_t mem_id[64]; uint32_t mem_w[64]; uint8_t steps[FREE_MAX]; };
+struct WaveScratch { uint32_t cnt[FREE_MAX]; uint32_t sch[FREE_MAX]; uint32_t mem_id[64]; uint32_t mem_w[64]; uint8_t steps[FREE_MAX]; uint8_t mk[FREE_MAX]; };
 
-// One member list of one item over the marked steps of the chunk: the (member, marked step) pairs [p_lo, p_hi) are
-// spread densely over the 64 lanes (the draws are Philox-bound -- 20 quarter-rate multiplies each -- so idle lanes
-// are what costs).  ws.steps: the item's marked steps in order, S of them; ws.cnt / ws.sch: the item's / the school's
-// Infected per step.  kind 0 residents, 1 workers, 2 room participants.
+// One member list of one item over the marked steps of the chunk.  Two consecutive time steps 2k, 2k+1 share one Philox block
+// (RNG contract: the even step takes words 0-1, the odd one words 2-3), so the unit of work is a (member, step PAIR) slot: the
+// slots [p_lo, p_hi) are spread densely over the 64 lanes (the draws are Philox-bound -- 20 quarter-rate multiplies a block --
+// so idle lanes and blocks used for one draw only are what costs).  ws.steps / ws.mk: the item's slots in order (first step of the
+// slot + 1, which of its two steps are marked), S of them; ws.cnt / ws.sch: the item's / the school's Infected per step.
+// kind 0 residents, 1 workers, 2 room participants.
 // pre_m / pre_w: members lo + pre_base + lane of the list and their words when the caller has already fetched them (have_pre).
 __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, WaveScratch &ws, const uint32_t *idx,
                                              uint32_t lo, uint32_t p_lo, uint32_t p_hi, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0,
                                              bool have_pre = false, uint32_t pre_m = 0u, uint32_t pre_w = 0u, uint32_t pre_base = 0u)
 {
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
-    // members touched by the pairs [p_lo, p_hi): staged in LDS 64 at a time -- every member recurs once per marked step
+    // members touched by the slots [p_lo, p_hi): staged in LDS 64 at a time -- every member recurs once per slot
     const uint32_t m_first = p_lo / S, m_last = (p_hi - 1u) / S;
     for (uint32_t mb = m_first; mb <= m_last; mb += 64u) {
         __builtin_amdgcn_wave_barrier();
@@ -762,41 +764,72 @@ __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const Chu
         __builtin_amdgcn_wave_barrier();
         const uint32_t q_lo = max(p_lo, mb * S), q_hi = min(p_hi, (mb + 64u) * S);
         for (uint32_t p = q_lo + lane; p < q_hi; p += 64u) {
-            const uint32_t um = p / S, j = ws.steps[p - um * S];
+            const uint32_t um = p / S, si = p - um * S;
             const uint32_t m = ws.mem_id[um - mb], w = ws.mem_w[um - mb];
-            const uint32_t te = CW_TE(w), s = t0 + j;
+            const uint32_t te = CW_TE(w);
             if (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) continue;
-            // Susceptible when this list is walked in step s: never exposed, or so far only exposed by something that
-            // comes later (a later step, or a bus of this step) -- that exposure may be undercut
-            if (w <= CW_MAKE(s + TE_BIAS, w & CW_KEEP)) continue;
-            if (j > CW_VAX_REL(w)) continue;                                                // Vaccinated by then (k_chunk_vax)
-            const uint32_t at_work = sm.dec[j].at_work, mask = sm.dec[j].mask;
-            const bool same = w & FL_SAME_AREA;
-            if (kind == 0u) { if (at_work && (w & FL_HAS_WORK) && !same) continue; }       // simulator.rs:324
-            else if (!at_work && !same) continue;
-            const uint32_t cnt = ws.cnt[j];
-            const uint32_t nn = kind == 2u ? ws.sch[j] : cnt;                               // exposure_count: infected in the building
-            const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
-            const uint64_t thr = sm.thr[row * 256u + (nn & 255u)];
+            const uint32_t jj = ws.steps[si], mk = ws.mk[si];                 // the slot's steps are jj - 1 (even time step) and jj (odd)
+            const uint32_t vrel = CW_VAX_REL(w);
+            bool act[2]; uint64_t thr[2]; uint32_t cnt[2];
+#pragma unroll
+            for (uint32_t h = 0; h < 2u; ++h) {
+                act[h] = false; thr[h] = 0ull; cnt[h] = 0u;
+                if (!((mk >> h) & 1u)) continue;
+                const uint32_t j = jj - 1u + h, s = t0 + j;
+                // Susceptible when this list is walked in step s: never exposed, or so far only exposed by something that
+                // comes later (a later step, or a bus of this step) -- that exposure may be undercut
+                if (w <= CW_MAKE(s + TE_BIAS, w & CW_KEEP)) continue;
+                if (j > vrel) continue;                                                     // Vaccinated by then (k_chunk_vax)
+                const uint32_t at_work = sm.dec[j].at_work, mask = sm.dec[j].mask;
+                const bool same = w & FL_SAME_AREA;
+                if (kind == 0u) { if (at_work && (w & FL_HAS_WORK) && !same) continue; }   // simulator.rs:324
+                else if (!at_work && !same) continue;
+                cnt[h] = ws.cnt[j];
+                const uint32_t nn = kind == 2u ? ws.sch[j] : cnt[h];                        // exposure_count: infected in the building
+                const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
+                thr[h] = sm.thr[row * 256u + (nn & 255u)];
+                act[h] = true;
+            }
+            if (!act[0] && !act[1]) continue;
             const uint32_t gid = d.id_base + m;
-            bool hit = false;
-            if (kind == 2u) { for (uint32_t k = 0; k < cnt && !hit; ++k) hit = esim_u53(seed, gid, s, ESIM_SLOT_ROOM0 + k) < thr; }
-            else hit = esim_u53(seed, gid, s, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK) < thr;
-            if (hit) expose_min(d, ctrl, m, w, s, 0u);
+            const uint32_t s_blk = t0 + jj - (act[0] ? 1u : 0u);              // any step of the slot names its block
+            bool hit0 = false, hit1 = false;
+            if (kind == 2u) {
+                // School::find_exposures: one draw per Infected in the room (building.rs:494-522)
+                const uint32_t kmax = max(act[0] ? cnt[0] : 0u, act[1] ? cnt[1] : 0u);
+                for (uint32_t k = 0; k < kmax && !hit0; ++k) {
+                    const philox_out o = esim_draw_block(seed, gid, s_blk, ESIM_SLOT_ROOM0 + k);
+                    if (act[0] && k < cnt[0]) hit0 = ((((uint64_t)o.w0 << 32) | o.w1) >> 11) < thr[0];
+                    if (act[1] && k < cnt[1] && !hit1) hit1 = ((((uint64_t)o.w2 << 32) | o.w3) >> 11) < thr[1];
+                }
+            } else {
+                const philox_out o = esim_draw_block(seed, gid, s_blk, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK);
+                hit0 = act[0] && ((((uint64_t)o.w0 << 32) | o.w1) >> 11) < thr[0];
+                hit1 = act[1] && ((((uint64_t)o.w2 << 32) | o.w3) >> 11) < thr[1];
+            }
+            if (hit0) expose_min(d, ctrl, m, w, t0 + jj - 1u, 0u);             // (the earlier of the two wins anyway)
+            else if (hit1) expose_min(d, ctrl, m, w, t0 + jj, 0u);
         }
     }
 }
 
-// The marked steps of item v, in order, and its per-step counts, into this wavefront's scratch.  Returns S.
-__device__ __forceinline__ uint32_t item_steps_regs(uint32_t c0, uint32_t c1, uint32_t lane, WaveScratch &ws)
+// The marked steps of item v as (even, odd) time-step slots, in order, and its per-step counts, into this wavefront's scratch.
+// Returns S, the number of slots with a marked step.
+__device__ __forceinline__ uint32_t item_steps_regs(uint32_t c0, uint32_t c1, uint32_t lane, WaveScratch &ws, uint32_t t0)
 {
     ws.cnt[lane] = c0;
     if (lane < FREE_MAX - 64u) ws.cnt[64u + lane] = c1;
     const unsigned long long b0 = __ballot(c0 != 0u), b1 = __ballot(c1 != 0u);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    if (c0) ws.steps[__popcll(b0 & lt)] = (uint8_t)lane;
-    if (c1) ws.steps[__popcll(b0) + __popcll(b1 & lt)] = (uint8_t)(64u + lane);
-    return (uint32_t)(__popcll(b0) + __popcll(b1));
+    // lane L looks at the slot whose even time step is step je = 2L - (t0 & 1) of the chunk (je = -1: only its odd step 0 exists)
+    const int je = 2 * (int)lane - (int)(t0 & 1u);
+    auto marked = [&](int j) -> uint32_t {
+        if (j < 0 || j >= (int)FREE_MAX) return 0u;
+        return (uint32_t)(((j < 64 ? b0 >> j : b1 >> (j - 64))) & 1ull);
+    };
+    const uint32_t mk = lane <= (FREE_MAX + 1u) / 2u ? (marked(je) | (marked(je + 1) << 1)) : 0u;
+    const unsigned long long present = __ballot(mk != 0u);
+    if (mk) { const uint32_t i = (uint32_t)__popcll(present & ((1ull << lane) - 1ull)); ws.steps[i] = (uint8_t)(je + 1); ws.mk[i] = (uint8_t)mk; }
+    return (uint32_t)__popcll(present);
 }
 
 __device__ __forceinline__ uint32_t fetch_slot(const Dev &d, uint32_t slot, uint32_t lane);
@@ -968,7 +1001,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
             if (lane < n_wrk) wm = d.wrk_idx[it.b_lo + lane];
             if (lane < n_res) rw = d.cit[rm];
             if (lane < n_wrk) ww = d.cit[wm];
-            const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws);
+            const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws, t0);
             __builtin_amdgcn_wave_barrier();
             // Household / Workplace::find_exposures: every registered occupant (building.rs:202-204,278-280)
             const UnitSrc src = { it.slot, it.link, FX(x, 7) };
@@ -980,7 +1013,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
             if (lane < n_mem) mm = d.room_idx[it.a_lo + lane];
             school_counts(d, it.link, lane, n, q0, q1, ws);
             if (lane < n_mem) mw = d.cit[mm];
-            const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws);
+            const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws, t0);
             __builtin_amdgcn_wave_barrier();
             // School::find_exposures: the room once per infected in it (building.rs:494-522)
             const UnitSrc src = { it.slot, it.link, FX(x, 7) };
@@ -1118,7 +1151,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
             if (lane < FREE_MAX - 64u) ws.sch[64u + lane] = s1;
         }
         const uint32_t *idx = kind == 2u ? d.room_idx : kind == 1u ? d.wrk_idx : d.res_idx;
-        const uint32_t S = item_steps_regs(c0, c1, lane, ws);
+        const uint32_t S = item_steps_regs(c0, c1, lane, ws, t0);
         __builtin_amdgcn_wave_barrier();
         const uint32_t pairs = n_mem * S;
         member_pairs(d, ctrl, sm, ws, idx, lo, p_lo, min(pairs, p_lo + UNIT_PAIRS), lane, kind, S, t0, true, mid, mw, mf);

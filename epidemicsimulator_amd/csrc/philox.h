@@ -40,11 +40,21 @@ ESIM_HD philox_out philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t
     return o;
 }
 
-// 53-bit integer of the uniform draw for (citizen, step, slot): uniform = u53 * 2^-53.
+// 53-bit integer of the exposure draw for (citizen, step, slot): uniform = u53 * 2^-53.  Steps 2k and 2k+1 share the block
+// (citizen, k, slot): the even step takes words (0,1), the odd one (2,3) -- all 128 bits of a block are used.
+ESIM_HD uint64_t esim_u53_of(const philox_out &o, uint32_t step)
+{
+    return (step & 1u) ? ((((uint64_t)o.w2 << 32) | o.w3) >> 11) : ((((uint64_t)o.w0 << 32) | o.w1) >> 11);
+}
+
+ESIM_HD philox_out esim_draw_block(uint64_t seed, uint32_t citizen, uint32_t step, uint32_t slot)
+{
+    return philox4x32_10(citizen, step >> 1, slot, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
 ESIM_HD uint64_t esim_u53(uint64_t seed, uint32_t citizen, uint32_t step, uint32_t slot)
 {
-    philox_out o = philox4x32_10(citizen, step, slot, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
-    return (((uint64_t)o.w0 << 32) | o.w1) >> 11;
+    return esim_u53_of(esim_draw_block(seed, citizen, step, slot), step);
 }
 
 // draw slots (RNG contract)

@@ -25,10 +25,11 @@
  *
  * RNG CONTRACT (shared, by specification, with the HIP implementation):
  *   block(c0,c1,c2,c3) = Philox4x32-10(counter=(c0,c1,c2,c3), key=(seed_lo,seed_hi))
- *   u53(block)  = ((w0 << 32 | w1) >> 11)                    -- 53-bit integer
+ *   u53(a, b)   = ((a << 32 | b) >> 11)                      -- 53-bit integer
  *   uniform     = u53 * 2^-53  in [0,1)
  *   exposure draw for citizen g (GLOBAL index) in step t, slot s:
- *        block(g, t, s, 0);  success  <=>  uniform < q   (strict, citizen.rs:242)
+ *        (w0,w1,w2,w3) = block(g, t >> 1, s, 0);  u53(w0,w1) for even t, u53(w2,w3) for odd t -- two steps per block, all
+ *        128 bits used;  success  <=>  uniform < q   (strict, citizen.rs:242)
  *        s = 0  draw from the home building's list          (building.rs:202)
  *        s = 1  draw from a non-school work building's list (building.rs:278)
  *        s = 2  draw on a bus                               (simulator.rs:436)

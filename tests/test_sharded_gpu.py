@@ -148,18 +148,18 @@ def test_bench_two_ranks_on_one_gpu():
     port = free_port()
     env = dict(os.environ, ESIM_BENCH_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "900", "--warmup", "24",
+           "--master-port", str(port), os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "1300", "--warmup", "24",
            "--preset", "york", "--transport", "callback"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["steps"] == 900 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["steps"] == 1300 and d["scaling"] == "strong" and d["value"] > 0
     assert sum(d["config"]["citizens_per_gpu"]) == 197603 and d["config"]["shared_buildings"] > 0
     assert d["config"]["collectives"] > 0 and d["config"]["chunk_steps"] > 0
-    assert d["golden_check"]["match"] and d["golden_check"]["records_compared"] >= 100 + 18      # first 100 records + every 50th up to 900
+    assert d["golden_check"]["match"] and d["golden_check"]["records_compared"] >= 100 + 24      # first 100 records + every 50th up to 1300
     fr = d["final_record"]
-    assert fr["time_step"] == 900 and fr["vaccinated"] > 0
+    assert fr["time_step"] == 1300 and fr["vaccinated"] > 0          # the programme starts at step 1099
     assert fr["susceptible"] + fr["exposed"] + fr["infected"] + fr["recovered"] + fr["vaccinated"] == 197603
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
 
@@ -175,5 +175,5 @@ def test_bench_one_gpu_line():
         assert k in d, k
     assert d["steps"] == 20 and d["golden_check"]["records_compared"] == 20
     assert d["full_run"]["steps"] == 5000 and d["full_run"]["golden_check"]["records_compared"] == 200
-    assert d["full_run"]["steps_with_vaccination_active"] > 4000 and d["full_run"]["sequential_steps"] < 50
+    assert d["full_run"]["steps_with_vaccination_active"] > 3800 and d["full_run"]["sequential_steps"] < 50
     assert d["cpu_baseline"]["kind"] == "reference-shaped" and d["cpu_baseline"]["records_match_gpu"]
