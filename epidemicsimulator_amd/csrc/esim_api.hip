@@ -384,6 +384,17 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if ((rc = dev_alloc(c, &d.units, (size_t)d.unit_qcap * SUBQ))) return rc;
         if ((rc = dev_alloc(c, &d.route_pairs, (size_t)d.items_cap * 2u))) return rc;
         if ((rc = dev_alloc(c, &d.route_pairs_big, (size_t)d.items_cap * 2u))) return rc;
+        {
+            std::vector<uint32_t> ovf_off(res_off.size());
+            for (size_t i = 0; i < res_off.size(); ++i) ovf_off[i] = res_off[i] + wrk_off[i];
+            if ((rc = dev_upload(c, &d.ovf_off, ovf_off.data(), ovf_off.size()))) return rc;
+            d.ovf_room_base = ovf_off.back();
+            if ((rc = dev_alloc(c, &d.ovf, (size_t)d.ovf_room_base + room_off.back() + 1u))) return rc;
+        }
+        if ((rc = dev_alloc(c, &d.big_list, d.items_cap))) return rc;
+        if ((rc = dev_alloc(c, &d.big_cnt, 16384u))) return rc;
+        if ((rc = dev_alloc(c, &d.used_pref, CHUNK_WAVES_MAX + 1u))) return rc;
+        HIP_TRY(c, hipMemset(d.big_cnt, 0, sizeof(uint32_t) * 16384u));
         if ((rc = dev_alloc(c, &d.pair_cnt, 16384u))) return rc;
         if ((rc = dev_alloc(c, &d.used_cnt, 16384u))) return rc;
         HIP_TRY(c, hipMemset(d.used_cnt, 0, sizeof(uint32_t) * 16384u));
@@ -473,7 +484,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     c->grid_infected = 1024;
     c->grid_expose = 1024;
     if (const char *e = std::getenv("ESIM_GRID_INFECTED")) c->grid_infected = (uint32_t)std::max(1, std::atoi(e));   // tuning knobs
-    if (const char *e = std::getenv("ESIM_GRID_CHUNK")) c->grid_chunk = (uint32_t)std::min(4096, std::max(16, std::atoi(e) / 16 * 16));   // whole groups of 64 wavefronts
+    if (const char *e = std::getenv("ESIM_GRID_CHUNK")) c->grid_chunk = (uint32_t)std::min((int)(CHUNK_WAVES_MAX * 64u / TPB), std::max(16, std::atoi(e) / 16 * 16));   // whole groups of 64 wavefronts
     if (const char *e = std::getenv("ESIM_GRID_EXPOSE")) c->grid_expose = (uint32_t)std::max(1, std::atoi(e));
     c->uploaded = true;
     return esim_reset(ctx);
@@ -681,6 +692,7 @@ void enqueue_parallel_chunk(esim_ctx_impl *c, int then_next, uint32_t limit_t)
     Dev &d = c->d;
     const bool small = c->last_chunk_pairs < 1024u;
     hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_fold, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     if (!small) hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);
@@ -699,6 +711,7 @@ void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
     hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 0);
     hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_fold, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);
@@ -1084,6 +1097,7 @@ int enqueue_sharded_chunk(esim_ctx_impl *c, uint32_t limit_t, bool vax)
     if ((rc = exchange(c, 2))) return rc;
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 1);
     hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_fold, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);

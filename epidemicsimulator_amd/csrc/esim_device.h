@@ -113,6 +113,8 @@ struct UnitRec { uint32_t slot, link, lo, n_mem, code, own, m_first, pad; };
 // An item of a time-parallel chunk: a building (a = residents, b = workers, aux = type), a school room (a =
 // participants, aux = its school building) or a route.
 struct ItemRec { uint32_t id, a_lo, a_hi, b_lo, b_hi, aux, link, own; };   // link: a room's school item; own: the claimer's interval record
+#define CHUNK_WAVES_MAX 4096u      // wavefronts of a chunk-pass kernel (1024 workgroups of 256)
+#define SLOT_COUNTERS_ONLY 0x40000000u // slot_state of a school building: no interval records, everybody counted in `vec`
 #define ITEM_RECS 7u               // interval records an item holds besides its claimer's
 
 // What is in force during one step of a pipelined chunk (k_decide fills dec[0..chunk_ok]).
@@ -159,6 +161,14 @@ struct Dev {
     uint32_t *pair_cnt;         // [wavefronts of k_chunk_marks]
     uint32_t *used_cnt;         // [wavefronts of k_chunk_marks] item ids the wavefront handed out
     uint32_t *route_pairs_big;  // [2 * items_cap] the same for longer routes, one shared list
+    // interval records beyond a slot's ITEM_RECS: a building's go to ovf[ovf_off[b] ...) (room for one per resident and worker), a
+    // room's to ovf[ovf_room_base + room_off[r] ...); k_chunk_fold sums them into `vec` before the draw pass
+    const uint32_t *ovf_off;    // [n_bld + 1] res_off + wrk_off
+    uint32_t ovf_room_base;     // ovf_off[n_bld]
+    uint32_t *ovf;              // [ovf_room_base + room_off[n_room]]
+    uint32_t *big_list;         // [items_cap] slots with records in `ovf`, by the wavefront of k_chunk_marks that saw the first
+    uint32_t *big_cnt;          // [wavefronts of k_chunk_marks]
+    uint32_t *used_pref;        // [CHUNK_WAVES_MAX + 1] prefix sums of used_cnt (k_chunk_fold)
     uint32_t unit_qcap;
     uint32_t *newexp;           // [SUBQ][newexp_cap] citizens exposed in the chunk, by id & 63
     uint32_t newexp_cap;

@@ -527,8 +527,22 @@ __device__ __forceinline__ uint32_t where_in_step(const Dev &d, uint32_t w, uint
     return (q.at_work && (w & FL_HAS_WORK)) ? 2u : 1u;
 }
 
-// generate_exposures (simulator.rs:181-198) for every step of the chunk: one wavefront per citizen that is
-// Infected somewhere in the chunk; lanes are the steps (two rounds of 64).
+// A set of steps of a chunk (FREE_MAX = 96 bits).
+struct M96 { unsigned long long lo; uint32_t hi; };
+__device__ __forceinline__ M96 m96_and(M96 a, M96 b) { return M96{ a.lo & b.lo, a.hi & b.hi }; }
+__device__ __forceinline__ M96 m96_andn(M96 a, M96 b) { return M96{ a.lo & ~b.lo, a.hi & ~b.hi }; }
+__device__ __forceinline__ bool m96_any(M96 a) { return a.lo != 0ull || a.hi != 0u; }
+// steps a..b (a <= b < 96)
+__device__ __forceinline__ M96 m96_range(uint32_t a, uint32_t b)
+{
+    M96 r = { 0ull, 0u };
+    if (a < 64u) { const uint32_t e = min(b, 63u); r.lo = (e == 63u ? ~0ull : ((1ull << (e + 1u)) - 1ull)) & (~0ull << a); }
+    if (b >= 64u) { const uint32_t s0 = a > 64u ? a - 64u : 0u, e = min(b - 64u, 31u); r.hi = (e == 31u ? ~0u : ((1u << (e + 1u)) - 1u)) & (~0u << s0); }
+    return r;
+}
+
+// generate_exposures (simulator.rs:181-198) for every step of the chunk: one LANE per citizen that is Infected somewhere in
+// the chunk.
 __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
 {
     Ctrl *ctrl = d.ctrl;
@@ -557,161 +571,316 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
     uint32_t next_id = wave * per_wave;
     const Decision q0 = lane < n ? d.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
     const Decision q1 = 64u + lane < n ? d.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
-    // The steps of the chunk in which riders are on a bus, in order (at most CHUNK_BUS_STEPS, k_decide): a route item keeps
-    // one bit per such step -- "an Infected rider of this route has registered the (route, step) pair".
-    const unsigned long long busm0 = __ballot(lane < n && q0.bus_dir != 0u), busm1 = __ballot(64u + lane < n && q1.bus_dir != 0u);
+    // The chunk's schedule as step masks (wavefront-uniform): the steps in which those with a work place are at work, and the
+    // steps in which riders are on a bus (at most CHUNK_BUS_STEPS, k_decide: a route item keeps one bit per such step -- "an
+    // Infected rider of this route has registered the (route, step) pair").
+    const M96 AW = { __ballot(lane < n && q0.at_work != 0u), (uint32_t)__ballot(64u + lane < n && q1.at_work != 0u) };
+    const M96 BUS = { __ballot(lane < n && q0.bus_dir != 0u), (uint32_t)__ballot(64u + lane < n && q1.bus_dir != 0u) };
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const uint32_t bidx0 = (uint32_t)__popcll(busm0 & lt), bidx1 = (uint32_t)(__popcll(busm0) + __popcll(busm1 & lt));   // index of my step among them
-    // lanes 0..3 own one key each: home building, work building, room, route.  The entry after this one is fetched
-    // (log entry, word, the lane's key source) before the work on this one: the hash claim's round trips overlap it.
-    const uint32_t *key_src = lane == 0 ? d.home : lane == 1 ? d.work : lane == 2 ? d.room : d.route_of;
     const uint32_t pm0 = PROF_NOW();
     uint32_t p_entries = 0u;
     uint32_t my_pairs = 0u;                                                   // (route, bus step) pairs this wavefront registered
-    uint32_t c_n = 0u, w_n = 0u, k_n = 0u;
-    if (i0 + wave < i1) { c_n = d.log[i0 + wave]; w_n = d.cit[c_n]; if (lane < 4u) k_n = key_src[c_n]; }
+    uint32_t my_big = 0u;                                                     // slots this wavefront listed for k_chunk_fold
     uint32_t ps[5] = { 0u, 0u, 0u, 0u, 0u };                                   // diagnostics: time per stage
-    uint32_t ps_alu = 0u;
-    const uint32_t pm_loop = PROF_NOW();
-    auto process = [&](const uint32_t w, const uint32_t ksrc, const bool remote, const uint32_t pa) {
-        const uint32_t p0 = lane < n ? where_in_step(d, w, t0, lane, q0) : 0u;
-        const uint32_t p1 = 64u + lane < n ? where_in_step(d, w, t0, 64u + lane, q1) : 0u;
-        // (a commuter from another shard only counts where it works: its home and its route are its own shard's business)
-        const bool any_home = !remote && __any((p0 | p1) & 1u), any_work = __any((p0 | p1) & 2u), any_bus = !remote && __any((p0 | p1) & 4u);
-        const bool school = w & FL_WORK_SCHOOL;
-        if (!any_home && !any_work && !any_bus) return;
-        ++p_entries;
-        const uint32_t pb = PROF_NOW();
-        // the citizen is Infected in steps [a, b] of the chunk (one stretch: disease.rs:60-65); where it stands in each of
-        // them follows from the record's flags and the step's schedule (iv_present)
-        const int a_abs = (int)CW_TE(w) - (int)TE_BIAS + (int)d.exposed_time + 1;
-        const uint32_t iv_a = a_abs > (int)t0 ? (uint32_t)(a_abs - (int)t0) : 0u;
-        const uint32_t iv_b = min(min((uint32_t)(a_abs + (int)d.infected_time - (int)t0), n - 1u), CW_VAX_REL(w));   // (CW_VAX_NONE is the largest value)
-        const uint32_t iv = IV_VALID | iv_a | (iv_b << 7) | ((w & FL_USES_PT) ? IV_PT : 0u) | ((w & FL_HAS_WORK) ? IV_HW : 0u) |
-                            ((lane == 1u || lane == 2u) ? IV_AS_WORK : 0u);
-        unsigned long long key = HKEY_EMPTY;
-        if (lane == 0 && any_home) key = ksrc;
-        if (lane == 1 && any_work) key = ksrc;
-        if (lane == 2 && any_work && school && ksrc != 0xFFFFFFFFu) key = (unsigned long long)d.n_bld + ksrc;   // (a remote commuter's room may have no member here)
-        if (lane == 3 && any_bus) key = (unsigned long long)d.n_bld + d.n_room + ksrc;
-        uint32_t slot = 0u;
-        bool pending = false, claimed = false;
-        const uint32_t pb2 = PROF_NOW();
-        if (key != HKEY_EMPTY) claimed = item_probe(d, ctrl, key, slot, pending);
-        const unsigned long long cm = __ballot(claimed);
-        const uint32_t pc = PROF_NOW();
-        ps_alu += pb2 - pb;
-        const uint32_t s_home = __shfl(slot, 0, 64), s_work = __shfl(slot, 1, 64), s_room = __shfl(slot, 2, 64);
-        if (claimed) {
-            const uint32_t v = next_id + (uint32_t)__popcll(cm & lt);
-            d.hitems[v] = slot;
-            // what the draw pass needs of the item; the claimer's own stretch travels in it, and a room's record names the
-            // slot of its school (the citizen's work building, lane 1)
-            const uint32_t id = (uint32_t)key;
-            // (a school's counts are looked up by slot from its rooms, so even its claimer's stretch goes into a slot record)
-            ItemRec rec = { id, 0u, 0u, 0u, 0u, 0u, lane == 2u ? s_work : 0xFFFFFFFFu, (lane < 3u && !(lane == 1u && school)) ? iv : 0u };
-            // (pointer selects, not branches: the loads of a building lane and of a room lane go out together)
-            const bool is_bld = id < d.n_bld, is_room = !is_bld && id < d.n_bld + d.n_room;
-            if (is_bld || is_room) {
-                const uint32_t r = is_bld ? id : id - d.n_bld;
-                const uint32_t *pa = (is_bld ? d.res_off : d.room_off) + r;
-                const uint32_t a_lo = pa[0], a_hi = pa[1];
-                const uint32_t b_lo = is_bld ? d.wrk_off[r] : 0u, b_hi = is_bld ? d.wrk_off[r + 1] : 0u;
-                const uint32_t aux = is_bld ? (uint32_t)d.bld_type[r] : d.room_bld[r];
-                rec.a_lo = a_lo; rec.a_hi = a_hi; rec.b_lo = b_lo; rec.b_hi = b_hi; rec.aux = aux;
+    // ONE LANE PER INFECTED CITIZEN: the pass is a chain of dependent round trips (log entry -> word and keys -> hash claim ->
+    // the item's lists / a record position -> the record), so what it needs is requests in flight, not lanes per citizen.
+    // Where a citizen stands in each step follows from its Infected stretch and the schedule masks with a few 96-bit
+    // operations.  Entry idx of the chunk's log slice (then of the commuters the other shards sent) belongs to wavefront
+    // idx % n_waves -- every wavefront gets the same share, whatever the number of entries, and with it the same share of item
+    // ids and of the draw pass's work.
+    const uint32_t E = i1 - i0, total = E + n_remote;
+    for (uint32_t round = 0; wave + n_waves * (round * 64u) < total; ++round) {
+        const uint32_t pa = PROF_NOW();
+        const uint32_t idx = wave + n_waves * (round * 64u + lane);
+        bool act = idx < total;
+        const bool remote = act && idx >= E;
+        uint32_t c = 0u, w = 0u, r_bld = 0xFFFFFFFFu, r_room = 0xFFFFFFFFu;
+        if (act && !remote) { c = d.log[i0 + idx]; w = d.cit[c]; }
+        if (remote) {
+            // Sharded: the Infected commuters the other shards sent (k_shared_pack, all-gathered): each stands in a building
+            // (and room) that has members here too; it enters the map like a local citizen's work building and room.
+            uint32_t e = idx - E;
+            const uint32_t *seg = nullptr;
+            for (uint32_t r = 0; r < d.world; ++r) {
+                if (r == d.rank) continue;
+                const uint32_t *sg = d.xs + (size_t)r * (1u + 3u * d.xs_cap);
+                const uint32_t cnt = min(sg[0], d.xs_cap);
+                if (e < cnt) { seg = sg; break; }
+                e -= cnt;
             }
-            d.item_rec[v] = rec;
+            act = false;
+            if (seg) {
+                w = seg[1u + 3u * e];
+                const uint32_t sb = seg[2u + 3u * e], sr = seg[3u + 3u * e];
+                const int32_t lb = d.shared_bld[sb];
+                if (lb >= 0) {                                                // (else nobody of that building lives here)
+                    act = true;
+                    r_bld = (uint32_t)lb;
+                    const int32_t lr = sr != 0xFFFFFFFFu ? d.shared_room[sr] : -1;
+                    if (lr >= 0) r_room = (uint32_t)lr;                       // (a remote commuter's room may have no member here)
+                }
+            }
         }
-        next_id += (uint32_t)__popcll(cm);
+        // the citizen is Infected in steps [a, b] of the chunk (one stretch: disease.rs:60-65), Vaccinated after the step its
+        // plan names (k_chunk_vax); where it stands in each of them (simulator.rs:181-198) follows from its flags and the schedule
+        const int a_abs = (int)CW_TE(w) - (int)TE_BIAS + (int)d.exposed_time + 1;
+        const int b_rel = a_abs + (int)d.infected_time - (int)t0;
+        const uint32_t iv_a = a_abs > (int)t0 ? (uint32_t)(a_abs - (int)t0) : 0u;
+        const uint32_t iv_b = b_rel < 0 ? 0u : min(min((uint32_t)b_rel, n - 1u), CW_VAX_REL(w));   // (CW_VAX_NONE is the largest value)
+        if (CW_TE(w) >= TE_RECOVERED || b_rel < 0 || iv_a > iv_b) act = false;
+        M96 I = m96_range(iv_a, iv_b);
+        if (!act) I = M96{ 0ull, 0u };
+        const M96 onbus = (w & FL_USES_PT) ? m96_and(I, BUS) : M96{ 0ull, 0u };
+        const M96 rest = m96_andn(I, onbus);
+        const M96 atw = (w & FL_HAS_WORK) ? m96_and(rest, AW) : M96{ 0ull, 0u };
+        const M96 ath = m96_andn(rest, atw);
+        // (a commuter from another shard only counts where it works: its home and its route are its own shard's business)
+        const bool any_home = !remote && m96_any(ath), any_work = m96_any(atw), any_bus = !remote && m96_any(onbus);
+        const bool school = w & FL_WORK_SCHOOL;
+        if (any_home || any_work || any_bus) ++p_entries;
+        // the four keys: home building, work building, room, route
+        uint32_t src[4] = { 0u, r_bld, r_room, 0u };
+        if (any_home) src[0] = d.home[c];
+        if (any_work && !remote) src[1] = d.work[c];
+        if (any_work && school && !remote) src[2] = d.room[c];
+        if (any_bus) src[3] = d.route_of[c];
+        unsigned long long key[4];
+        key[0] = any_home ? (unsigned long long)src[0] : HKEY_EMPTY;
+        key[1] = any_work ? (unsigned long long)src[1] : HKEY_EMPTY;
+        key[2] = (any_work && school && src[2] != 0xFFFFFFFFu) ? (unsigned long long)d.n_bld + src[2] : HKEY_EMPTY;
+        key[3] = any_bus ? (unsigned long long)d.n_bld + d.n_room + src[3] : HKEY_EMPTY;
+        const uint32_t pb = PROF_NOW() + (uint32_t)(key[0] & 0ull) + (uint32_t)(key[1] & 0ull) + (uint32_t)(key[2] & 0ull) + (uint32_t)(key[3] & 0ull);
+        // claim or find the items: the first probes of all four keys go out together
+        uint32_t slot[4];
+        unsigned long long seen[4];
+        // (a look before the CAS: the hundreds of Infected of one school all ask for the same key, and compare-and-swaps on one
+        // address are served one after the other, loads are not -- a stale "empty" only costs the CAS it would have cost anyway)
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            slot[k] = hash64(key[k]) & (d.hcap - 1u);
+            seen[k] = key[k];
+            if (key[k] != HKEY_EMPTY) seen[k] = d.hkey[slot[k]];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+            if (key[k] != HKEY_EMPTY && seen[k] == HKEY_EMPTY) seen[k] = atomicCAS(&d.hkey[slot[k]], HKEY_EMPTY, key[k]);
+        bool claimed[4], pending[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            claimed[k] = false; pending[k] = false;
+            if (key[k] == HKEY_EMPTY) continue;
+            if (seen[k] == HKEY_EMPTY) claimed[k] = true;
+            else if (seen[k] == key[k]) pending[k] = true;
+            else {
+                // somebody else's key in the slot: linear probing
+                uint32_t h = slot[k];
+                bool found = false;
+                for (uint32_t probe = 1; probe < d.hcap && !found; ++probe) {
+                    h = (h + 1u) & (d.hcap - 1u);
+                    const unsigned long long old = atomicCAS(&d.hkey[h], HKEY_EMPTY, key[k]);
+                    if (old == HKEY_EMPTY) { claimed[k] = true; found = true; }
+                    else if (old == key[k]) { pending[k] = true; found = true; }
+                }
+                if (!found) { ctrl->error = (uint32_t)(-ESIM_ERANGE); key[k] = HKEY_EMPTY; h = 0u; }
+                slot[k] = h;
+            }
+        }
+        const uint32_t pc = PROF_NOW() + (slot[0] & 0u) + (slot[1] & 0u) + (slot[2] & 0u) + (slot[3] & 0u);
+        const uint32_t iv_home = IV_VALID | iv_a | (iv_b << 7) | ((w & FL_USES_PT) ? IV_PT : 0u) | ((w & FL_HAS_WORK) ? IV_HW : 0u);
+        const uint32_t iv_work = iv_home | IV_AS_WORK;
+        // the claimers take the next ids of this wavefront's range and write what the draw pass needs of the item; the claimer's
+        // own stretch travels in it (a school's counts are looked up by slot from its rooms, so even its claimer's stretch goes
+        // into a slot record), and a room's record names the slot of its school (the citizen's work building)
+        // (ids in citizen order, a citizen's items side by side: the draw pass walks a wavefront's items in id order, and a
+        // mix of short and long member lists along the way keeps its load even)
+        uint32_t before = 0u, n_claims = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) { const unsigned long long cm = __ballot(claimed[k]); before += (uint32_t)__popcll(cm & lt); n_claims += (uint32_t)__popcll(cm); }
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            if (claimed[k]) {
+                const uint32_t v = next_id + before++;
+                d.hitems[v] = slot[k];
+                const uint32_t id = (uint32_t)key[k];
+                ItemRec rec = { id, 0u, 0u, 0u, 0u, 0u, k == 2u ? slot[1] : 0xFFFFFFFFu,
+                                k == 0u ? iv_home : (k == 1u && !school) || k == 2u ? iv_work : 0u };
+                if (k == 0u || k == 1u) {
+                    rec.a_lo = d.res_off[id]; rec.a_hi = d.res_off[id + 1u];
+                    rec.b_lo = d.wrk_off[id]; rec.b_hi = d.wrk_off[id + 1u];
+                    rec.aux = (uint32_t)d.bld_type[id];
+                } else if (k == 2u) {
+                    const uint32_t r = id - d.n_bld;
+                    rec.a_lo = d.room_off[r]; rec.a_hi = d.room_off[r + 1u];
+                    rec.aux = d.room_bld[r];
+                }
+                d.item_rec[v] = rec;
+            }
+        }
+        next_id += n_claims;
         const uint32_t pd = PROF_NOW();
         // Somebody else's building / room: my stretch goes into one of the slot's ITEM_RECS records; when they are taken,
         // into its per-step counters (`vec`), one atomic per step.  The route: which of my bus steps nobody has registered yet.
         uint32_t mine = 0u;                                                   // bit i: I ride, Infected, in the i-th bus step of the chunk
         if (any_bus) {
-            const unsigned long long r0 = __ballot((p0 & 4u) != 0u), r1 = __ballot((p1 & 4u) != 0u);
-            for (unsigned long long m = busm0 & r0; m; m &= m - 1ull) mine |= 1u << __popcll(busm0 & ((m & (0ull - m)) - 1ull));
-            for (unsigned long long m = busm1 & r1; m; m &= m - 1ull) mine |= 1u << (__popcll(busm0) + __popcll(busm1 & ((m & (0ull - m)) - 1ull)));
+            uint32_t i = 0u;
+            for (unsigned long long m = BUS.lo; m; m &= m - 1ull, ++i) mine |= (uint32_t)((onbus.lo >> __builtin_ctzll(m)) & 1ull) << i;
+            for (uint32_t m = BUS.hi; m; m &= m - 1u, ++i) mine |= ((onbus.hi >> __builtin_ctz(m)) & 1u) << i;
         }
-        const bool add_rec = lane < 3u && (pending || (claimed && lane == 1u && school));
-        const bool reg_bus = lane == 3u && any_bus;
-        uint32_t old = 0u;
-        if (add_rec || reg_bus) {
-            // lanes 0..2 take a record position (+1), lane 3 sets its bus-step bits: two atomic instructions, one wait
-            if (reg_bus) old = atomicOr(&d.slot_state[slot], mine);
-            else old = atomicAdd(&d.slot_state[slot], 1u);
+        bool add_rec[3];
+        uint32_t old[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k) {
+            // (a school's Infected -- hundreds -- do not queue for record positions: they count themselves, see below)
+            add_rec[k] = pending[k] && !(k == 1u && school);
+            if (add_rec[k]) old[k] = atomicAdd(&d.slot_state[slot[k]], 1u);
         }
-        bool spill = false;
-        if (add_rec) { if (old < ITEM_RECS) d.slot_iv[(size_t)slot * 8u + old] = iv; else spill = true; }
-        const uint32_t new_bits = __shfl(reg_bus ? (mine & ~old) : 0u, 3, 64);
-        const bool sp_home = __shfl((int)spill, 0, 64), sp_work = __shfl((int)spill, 1, 64), sp_room = __shfl((int)spill, 2, 64);
-        const uint32_t pe = PROF_NOW();
-        if (sp_home) {
-            if (p0 & 1u) atomicAdd(&d.vec[(size_t)s_home * FREE_MAX + lane], 1u);
-            if (p1 & 1u) atomicAdd(&d.vec[(size_t)s_home * FREE_MAX + 64u + lane], 1u);
+        if (claimed[1] && school) d.slot_state[slot[1]] = SLOT_COUNTERS_ONLY;     // (tells item_counts and the clean-up)
+        if (any_bus && key[3] != HKEY_EMPTY) old[3] = atomicOr(&d.slot_state[slot[3]], mine);
+        // positions beyond ITEM_RECS: the record goes into the building's / room's own stretch of `ovf` (one place per member, so
+        // it cannot run out -- except for commuters from other shards, who are no members here: those add themselves to the
+        // slot's per-step counters, one atomic per step, which nobody has to wait for; so does everybody in a school
+        // building); the first to get there lists the slot for k_chunk_fold
+        bool direct[3], first[3];
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k) {
+            direct[k] = k == 1u && school && key[1] != HKEY_EMPTY; first[k] = false;
+            if (!add_rec[k]) continue;
+            const uint32_t iv = k == 0u ? iv_home : iv_work;
+            if (old[k] < ITEM_RECS) { d.slot_iv[(size_t)slot[k] * 8u + old[k]] = iv; continue; }
+            const uint32_t q = old[k] - ITEM_RECS, id = (uint32_t)key[k];
+            uint32_t base, cap;
+            if (k < 2u) { base = d.ovf_off[id]; cap = d.ovf_off[id + 1u] - base; }
+            else { const uint32_t r = id - d.n_bld; const uint32_t o = d.room_off[r]; base = d.ovf_room_base + o; cap = d.room_off[r + 1u] - o; }
+            if (q < cap) { d.ovf[base + q] = iv; first[k] = q == 0u; }
+            else direct[k] = true;
         }
-        if (sp_work) {
-            if (p0 & 2u) atomicAdd(&d.vec[(size_t)s_work * FREE_MAX + lane], 1u);
-            if (p1 & 2u) atomicAdd(&d.vec[(size_t)s_work * FREE_MAX + 64u + lane], 1u);
-        }
-        if (sp_room) {
-            if (p0 & 2u) atomicAdd(&d.vec[(size_t)s_room * FREE_MAX + lane], 1u);
-            if (p1 & 2u) atomicAdd(&d.vec[(size_t)s_room * FREE_MAX + 64u + lane], 1u);
-        }
-        if (new_bits) {
-            // register the (route, step) pairs that are new: k_chunk_draw ranks the riders of each once
-            const bool f0 = (p0 & 4u) && ((new_bits >> bidx0) & 1u), f1 = (p1 & 4u) && ((new_bits >> bidx1) & 1u);
-            const uint32_t rt = __shfl(ksrc, 3, 64);                          // the route itself, not its item: saves the pass a hop
-            const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
-            const uint32_t add = (uint32_t)(__popcll(m0) + __popcll(m1));     // <= CHUNK_BUS_STEPS (k_decide)
-            if (!(w & FL_BIG_ROUTE)) {
-                // this wavefront's own stretch of the list: no shared counter
-                uint32_t *list = d.route_pairs + (size_t)wave * 2u * per_wave;
-                if (my_pairs + add <= 2u * per_wave) {
-                    if (f0) list[my_pairs + (uint32_t)__popcll(m0 & lt)] = (rt << 7) | lane;
-                    if (f1) list[my_pairs + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1 & lt)] = (rt << 7) | (64u + lane);
-                    my_pairs += add;
-                } else if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE);
-            } else {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&d.hot[HOT_BIGPAIRS * HOT_STRIDE], add);
-                base = __shfl(base, 0, 64);
-                if (base + add <= 2u * d.items_cap) {
-                    if (f0) d.route_pairs_big[base + (uint32_t)__popcll(m0 & lt)] = (rt << 7) | lane;
-                    if (f1) d.route_pairs_big[base + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1 & lt)] = (rt << 7) | (64u + lane);
-                } else if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE);
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k) {
+            const unsigned long long fm = __ballot(first[k]);
+            if (first[k]) d.big_list[(size_t)wave * per_wave + my_big + (uint32_t)__popcll(fm & lt)] = slot[k];
+            my_big += (uint32_t)__popcll(fm);
+            const M96 at = k == 0u ? ath : atw;
+            for (unsigned long long sp = __ballot(direct[k]); sp; sp &= sp - 1ull) {
+                const int src_lane = __builtin_ctzll(sp);
+                const uint32_t sl = __shfl(slot[k], src_lane, 64), hi = __shfl(at.hi, src_lane, 64);
+                const unsigned long long lo = ((unsigned long long)__shfl((uint32_t)(at.lo >> 32), src_lane, 64) << 32) | __shfl((uint32_t)at.lo, src_lane, 64);
+                uint32_t *v = d.vec + (size_t)sl * FREE_MAX;
+                if ((lo >> lane) & 1ull) atomicAdd(&v[lane], 1u);
+                if (lane < 32u && ((hi >> lane) & 1u)) atomicAdd(&v[64u + lane], 1u);
             }
+        }
+        const uint32_t pe = PROF_NOW() + (old[0] & 0u) + (old[1] & 0u) + (old[2] & 0u) + (old[3] & 0u);
+        // register the (route, step) pairs that are new: k_chunk_draw ranks the riders of each once
+        const uint32_t new_bits = (any_bus && key[3] != HKEY_EMPTY) ? (mine & ~old[3]) : 0u;
+        if (__any(new_bits != 0u)) {
+            const bool big = w & FL_BIG_ROUTE;
+            const uint32_t rt = src[3];                                       // the route itself, not its item: saves the pass a hop
+            // routes of few riders: this wavefront's own stretch of the list, no shared counter; the others share one
+            uint32_t *list = d.route_pairs + (size_t)wave * 2u * per_wave;
+            uint32_t n_big = 0u;
+            for (uint32_t i = 0; i < CHUNK_BUS_STEPS; ++i) n_big += (uint32_t)__popcll(__ballot(big && ((new_bits >> i) & 1u)));
+            uint32_t big_base = 0u;
+            if (n_big) {
+                if (lane == 0) big_base = atomicAdd(&d.hot[HOT_BIGPAIRS * HOT_STRIDE], n_big);
+                big_base = __shfl(big_base, 0, 64);
+                if (big_base + n_big > 2u * d.items_cap) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); n_big = 0u; big_base = 0xFFFFFFFFu; }
+            }
+            uint32_t i = 0u;
+            auto put = [&](uint32_t j) {
+                const bool f = (new_bits >> i) & 1u;
+                const unsigned long long ms = __ballot(f && !big), mb = __ballot(f && big);
+                if (f && !big) {
+                    const uint32_t pos = my_pairs + (uint32_t)__popcll(ms & lt);
+                    if (pos < 2u * per_wave) list[pos] = (rt << 7) | j; else ctrl->error = (uint32_t)(-ESIM_ERANGE);
+                }
+                if (f && big && big_base != 0xFFFFFFFFu) d.route_pairs_big[big_base + (uint32_t)__popcll(mb & lt)] = (rt << 7) | j;
+                my_pairs += (uint32_t)__popcll(ms);
+                if (big_base != 0xFFFFFFFFu) big_base += (uint32_t)__popcll(mb);
+                ++i;
+            };
+            for (unsigned long long m = BUS.lo; m; m &= m - 1ull) put((uint32_t)__builtin_ctzll(m));
+            for (uint32_t m = BUS.hi; m; m &= m - 1u) put(64u + (uint32_t)__builtin_ctz(m));
+            my_pairs = min(my_pairs, 2u * per_wave);
         }
         { const uint32_t pf = PROF_NOW(); ps[0] += pb - pa; ps[1] += pc - pb; ps[2] += pd - pc; ps[3] += pe - pd; ps[4] += pf - pe; }
-    };
-    for (uint32_t e = i0 + wave; e < i1; e += n_waves) {
-        const uint32_t w = w_n, ksrc = k_n;
-        const uint32_t pa = PROF_NOW();
-        if (e + n_waves < i1) { c_n = d.log[e + n_waves]; w_n = d.cit[c_n]; if (lane < 4u) k_n = key_src[c_n]; }
-        process(w, ksrc, false, pa);
     }
-    // Sharded: the Infected commuters the other shards sent (k_shared_pack, all-gathered): each stands in a building (and room)
-    // that has members here too; it enters the map like a local citizen's work building and room.
-    if (d.world > 1u) {
-        uint32_t seen = 0u;                                                   // remote entries before this shard's segment
-        for (uint32_t r = 0; r < d.world; ++r) {
-            if (r == d.rank) continue;
-            const uint32_t *seg = d.xs + (size_t)r * (1u + 3u * d.xs_cap);
-            const uint32_t cnt = min(seg[0], d.xs_cap);
-            for (uint32_t e = (wave + n_waves - seen % n_waves) % n_waves; e < cnt; e += n_waves) {
-                const uint32_t w = seg[1u + 3u * e], sb = seg[2u + 3u * e], sr = seg[3u + 3u * e];
-                const int32_t lb = d.shared_bld[sb];
-                if (lb < 0) continue;                                         // nobody of that building lives here
-                const int32_t lr = sr != 0xFFFFFFFFu ? d.shared_room[sr] : -1;
-                process(w, lane == 1u ? (uint32_t)lb : lane == 2u ? (lr >= 0 ? (uint32_t)lr : 0xFFFFFFFFu) : 0u, true, PROF_NOW());
-            }
-            seen += cnt;
-        }
-    }
-    if (lane == 0) { d.pair_cnt[wave] = my_pairs; d.used_cnt[wave] = next_id - wave * per_wave; }
+    if (lane == 0) { d.pair_cnt[wave] = my_pairs; d.used_cnt[wave] = next_id - wave * per_wave; d.big_cnt[wave] = my_big; }
     const uint32_t pm1 = PROF_NOW();
     PROF_PUT(d, 8, pm0); PROF_PUT(d, 9, pm1); PROF_PUT(d, 10, p_entries);
     PROF_PUT(d, 11, ps[0]); PROF_PUT(d, 12, ps[1]); PROF_PUT(d, 13, ps[2]); PROF_PUT(d, 14, ps[3]); PROF_PUT(d, 15, ps[4]);
-    PROF_PUT(d, 6, pm_loop - pm0); PROF_PUT(d, 7, ps_alu); (void)ps_alu;
+    (void)p_entries; (void)ps;
+}
+
+// The interval records k_chunk_marks put into `ovf` (slots with more than ITEM_RECS of them: schools, large work places),
+// summed into the slots' per-step counters before the draw pass reads them.  One wavefront per listed slot, 64 records at a
+// time; each lane turns its record into the set of steps in which that citizen stands there, one ballot per step counts them.
+__global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
+{
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t n = ctrl->chunk_ok;
+    if (!ctrl->chunk_parallel || n == 0u) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    const uint32_t per_wave = ld(&ctrl->items_per_wave);
+    if ((unsigned long long)per_wave * n_waves > d.items_cap) return;
+    if (blockIdx.x == 0) {
+        // for k_chunk_draw: used_pref[k] = ids handed out by the wavefronts before k
+        __shared__ uint32_t s_pref[CHUNK_WAVES_MAX + 1u];
+        __shared__ uint32_t s_wtot[TPB / 64];
+        const uint32_t pf0 = PROF_NOW();
+        constexpr uint32_t RUN = CHUNK_WAVES_MAX / TPB;
+        const uint32_t run = (n_waves + TPB - 1u) / TPB, b = threadIdx.x * run;   // <= RUN
+        uint32_t cnt[RUN];
+        uint32_t sum = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < RUN; ++k) { cnt[k] = (k < run && b + k < n_waves) ? min(d.used_cnt[b + k], per_wave) : 0u; sum += cnt[k]; }
+        uint32_t x = sum;
+        for (uint32_t o = 1; o < 64u; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63u) s_wtot[threadIdx.x >> 6] = x;
+        if (threadIdx.x == 0) s_pref[0] = 0u;
+        __syncthreads();
+        const uint32_t pf1 = PROF_NOW();
+        uint32_t acc = x - sum;
+        for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) acc += s_wtot[k];
+#pragma unroll
+        for (uint32_t k = 0; k < RUN; ++k) if (k < run && b + k < n_waves) { acc += cnt[k]; s_pref[b + k + 1u] = acc; }
+        __syncthreads();
+        const uint32_t pf2 = PROF_NOW();
+        for (uint32_t w = threadIdx.x; w <= n_waves; w += TPB) d.used_pref[w] = s_pref[w];
+        BOOKS_PROF(d, 8, pf1 - pf0); BOOKS_PROF(d, 9, pf2 - pf1); BOOKS_PROF(d, 10, PROF_NOW() - pf2);
+        (void)pf0; (void)pf1; (void)pf2;
+    }
+    const uint32_t n_big = min(d.big_cnt[wave], per_wave);
+    if (n_big == 0u) return;
+    const Decision q0 = lane < n ? d.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
+    const Decision q1 = 64u + lane < n ? d.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
+    const M96 AW = { __ballot(lane < n && q0.at_work != 0u), (uint32_t)__ballot(64u + lane < n && q1.at_work != 0u) };
+    const M96 BUS = { __ballot(lane < n && q0.bus_dir != 0u), (uint32_t)__ballot(64u + lane < n && q1.bus_dir != 0u) };
+    for (uint32_t i = 0; i < n_big; ++i) {
+        const uint32_t slot = d.big_list[(size_t)wave * per_wave + i];
+        const uint32_t id = (uint32_t)d.hkey[slot], state = d.slot_state[slot];
+        uint32_t base, cap;
+        if (id < d.n_bld) { base = d.ovf_off[id]; cap = d.ovf_off[id + 1u] - base; }
+        else { const uint32_t r = id - d.n_bld; const uint32_t o = d.room_off[r]; base = d.ovf_room_base + o; cap = d.room_off[r + 1u] - o; }
+        const uint32_t n_ov = min(state > ITEM_RECS ? state - ITEM_RECS : 0u, cap);
+        uint32_t c0 = 0u, c1 = 0u;
+        for (uint32_t b = 0; b < n_ov; b += 64u) {
+            const uint32_t iv = b + lane < n_ov ? d.ovf[base + b + lane] : 0u;
+            // where this record's citizen stands, as in iv_present
+            M96 at = { 0ull, 0u };
+            if (iv & IV_VALID) {
+                const M96 I = m96_range(iv & 127u, (iv >> 7) & 127u);
+                const M96 rest = (iv & IV_PT) ? m96_andn(I, BUS) : I;
+                const M96 atw = (iv & IV_HW) ? m96_and(rest, AW) : M96{ 0ull, 0u };
+                at = (iv & IV_AS_WORK) ? atw : m96_andn(rest, atw);
+            }
+            for (uint32_t j = 0; j < n && j < 64u; ++j) { const uint32_t k = (uint32_t)__popcll(__ballot((at.lo >> j) & 1ull)); if (lane == j) c0 += k; }
+            for (uint32_t j = 64u; j < n; ++j) { const uint32_t k = (uint32_t)__popcll(__ballot((at.hi >> (j - 64u)) & 1u)); if (lane == j - 64u) c1 += k; }
+        }
+        uint32_t *v = d.vec + (size_t)slot * FREE_MAX;
+        if (lane < n && c0) v[lane] += c0;                                    // (the commuters' atomics of k_chunk_marks are done)
+        if (64u + lane < n && c1) v[64u + lane] += c1;
+    }
 }
 
 // A successful draw of citizen m in step s (bus: on public transport).
@@ -838,9 +1007,12 @@ __device__ __forceinline__ void item_counts(const Dev &d, uint32_t x, uint32_t s
 __device__ __forceinline__ void school_counts(const Dev &d, uint32_t s_sch, uint32_t lane, uint32_t n, const Decision &q0, const Decision &q1, WaveScratch &ws)
 {
     // s_sch: the hash slot of the room's school (k_chunk_marks left it in the room's record): infected in the whole school, per
-    // step.  All of a school's stretches are slot records (k_chunk_marks), so the slot alone gives the count.
+    // step.  Everybody Infected in a school building counts itself in the slot's per-step counters (k_chunk_marks).
     uint32_t c0 = 0u, c1 = 0u;
-    if (s_sch != 0xFFFFFFFFu) { const uint32_t x = fetch_slot(d, s_sch, lane); item_counts(d, x, s_sch, lane, n, q0, q1, c0, c1); }
+    if (s_sch != 0xFFFFFFFFu) {
+        if (lane < n) c0 = d.vec[(size_t)s_sch * FREE_MAX + lane];
+        if (64u + lane < n) c1 = d.vec[(size_t)s_sch * FREE_MAX + 64u + lane];
+    }
     ws.sch[lane] = c0;
     if (lane < FREE_MAX - 64u) ws.sch[64u + lane] = c1;
 }
@@ -911,10 +1083,11 @@ __device__ __forceinline__ void item_counts(const Dev &d, uint32_t x, uint32_t s
     const uint32_t state = FX(x, 16);
     c0 = 0u; c1 = 0u;
     if (state > ITEM_RECS) {
+        // (summed up by k_chunk_fold from the records beyond ITEM_RECS)
         if (lane < n) c0 = d.vec[(size_t)slot * FREE_MAX + lane];
         if (64u + lane < n) c1 = d.vec[(size_t)slot * FREE_MAX + 64u + lane];
     }
-    const uint32_t n_rec = state < ITEM_RECS ? state : ITEM_RECS;
+    const uint32_t n_rec = state >= SLOT_COUNTERS_ONLY ? 0u : state < ITEM_RECS ? state : ITEM_RECS;
     for (uint32_t k = 0; k < n_rec; ++k) {
         const uint32_t iv = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)(8u + k));
         if (lane < n) c0 += iv_present(iv, lane, q0);
@@ -945,22 +1118,39 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     Ctrl *ctrl = d.ctrl;
     const uint32_t t0 = ctrl->chunk_t0, n = ctrl->chunk_ok;
     if (!ctrl->chunk_parallel || n == 0u) return;
-    const uint32_t n_items = min(ld(&ctrl->n_items), d.items_cap);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;   // <= CHUNK_WAVES_MAX (esim_create)
     const uint32_t pt0 = PROF_NOW();
     uint32_t p_items = 0u, p_item_max = 0u;
-    // the items claimed by the wavefront of the same index in k_chunk_marks (same grid): the first used_cnt[wave] ids of
-    // [wave * per_wave, ...).  (Striding over all ids instead would pile the items onto the few wavefronts whose index
-    // matches the low ids of every range.)
+    // The wavefronts of k_chunk_marks (same grid) each handed out the first used_cnt[w] ids of [w * per_wave, ...): whoever
+    // reaches a key first claims its item, so the early wavefronts hold far more items than the late ones.  The pass
+    // therefore takes the items in id order as ONE dense sequence and every wavefront draws an equal stretch of it
+    // (k_chunk_fold left the prefix sums of used_cnt in used_pref).
     const uint32_t per_wave = ld(&ctrl->items_per_wave);
-    const uint32_t v_lo = wave * per_wave, v_cap = min(v_lo + per_wave, n_items);
-    const uint32_t used = d.used_cnt[wave];                                   // ids it handed out (needed only after the fetches below)
+    if ((unsigned long long)per_wave * n_waves > d.items_cap) return;          // (k_chunk_marks raised ESIM_ERANGE and left no items)
+    // this wavefront's stretch [d_lo, d_hi) of the T items, and the wavefront of k_chunk_marks that owns d_lo: the last one
+    // whose ids start at or before it -- first among every 64th, then among the 64 from there on
+    const uint32_t T = d.used_pref[n_waves];
+    const uint32_t coarse = d.used_pref[min(64u * lane, n_waves)];
+    const uint32_t Tq = T / n_waves, Tr = T % n_waves;                         // (T * wave / n_waves without 64-bit division)
+    const uint32_t d_lo = Tq * wave + Tr * wave / n_waves, d_hi = Tq * (wave + 1u) + Tr * (wave + 1u) / n_waves;
+    // lane l: where the ids of owner ow_base + l start in the dense sequence (a window of 64 owners, moved on when used up)
+    uint32_t ow_base = 64u * ((uint32_t)__popcll(__ballot(64u * lane < n_waves && coarse <= d_lo)) - 1u);
+    uint32_t win = d.used_pref[min(ow_base + lane, n_waves)];
+    uint32_t ow = ow_base + (uint32_t)__popcll(__ballot(ow_base + lane < n_waves && win <= d_lo)) - 1u;
+    // item id of dense index i; called with ascending i
+    auto id_of = [&](uint32_t i) -> uint32_t {
+        for (;;) {
+            const uint32_t rel = ow - ow_base;
+            if (rel == 63u) { ow_base = ow; win = d.used_pref[min(ow_base + lane, n_waves)]; continue; }
+            if (ow + 1u < n_waves && (uint32_t)__builtin_amdgcn_readlane((int)win, (int)(rel + 1u)) <= i) { ++ow; continue; }
+            return ow * per_wave + (i - (uint32_t)__builtin_amdgcn_readlane((int)win, (int)rel));
+        }
+    };
     // three items in flight: the record of the one after next (by id), the slot records of the next (by its slot), this one
     uint32_t id_cur = 0u, id_nxt = 0u, sl_cur = 0u;
-    if (v_lo < v_cap) id_cur = fetch_item(d, v_lo, lane);                      // (fetched before `used` is known: in bounds either way)
-    if (v_lo + 1u < v_cap) id_nxt = fetch_item(d, v_lo + 1u, lane);
-    const uint32_t v_hi = min(v_lo + used, v_cap);
+    if (d_lo < d_hi) id_cur = fetch_item(d, id_of(d_lo), lane);
+    if (d_lo + 1u < d_hi) id_nxt = fetch_item(d, id_of(d_lo + 1u), lane);
     // ... and the first look at the (route, bus step) pairs dealt to this wavefront (phase 2 below), so that they are here
     // when the items are done
     const uint32_t K = 2u * per_wave;                                          // pairs a stretch of the list can hold
@@ -978,17 +1168,17 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     WaveScratch &ws = wsc[threadIdx.x >> 6];
     const Decision q0 = lane < n ? sm.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
     const Decision q1 = 64u + lane < n ? sm.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
-    if (v_lo < v_hi) sl_cur = fetch_slot(d, FX(id_cur, 17), lane);
+    if (d_lo < d_hi) sl_cur = fetch_slot(d, FX(id_cur, 17), lane);
     if (have) { const uint32_t r = code_l >> 7; off_l = d.route_off[r]; sz_l = d.route_off[r + 1] - off_l; }
     const uint32_t pt1 = PROF_NOW();
     // (1) buildings and school rooms: one wavefront per item
-    for (uint32_t v = v_lo; v < v_hi; ++v) {
+    for (uint32_t v = d_lo; v < d_hi; ++v) {
         const uint32_t x = merge_fetch(id_cur, sl_cur, lane);
         id_cur = id_nxt;
-        if (v + 2u < v_hi) id_nxt = fetch_item(d, v + 2u, lane);
-        if (v + 1u < v_hi) sl_cur = fetch_slot(d, FX(id_cur, 17), lane);
+        if (v + 2u < d_hi) id_nxt = fetch_item(d, id_of(v + 2u), lane);
+        if (v + 1u < d_hi) sl_cur = fetch_slot(d, FX(id_cur, 17), lane);
         const ItemFetch it = decode_item(d, x, lane, n, q0, q1);
-        if (it.slot == ITEM_UNUSED) break;
+        if (it.slot == ITEM_UNUSED) continue;
         if (it.id >= route_base) continue;
         const uint32_t pi0 = PROF_NOW();
         (void)pi0; ++p_items;

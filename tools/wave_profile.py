@@ -12,7 +12,8 @@ buf = np.zeros(W * 16, np.uint32)
 khz = C.c_int(0)
 sim.lib.esim_prof_read.restype = C.c_int
 sim.lib.esim_prof_read.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_int)]
-for target in (96, 192, 960, 1056, 1920, 2880, 3840, 4800, 4896, 4992):
+targets = [int(x) for x in sys.argv[2:]] or [96, 192, 960, 1056, 1920, 2880, 3840, 4800, 4896, 4992]
+for target in targets:
     sim.run(target - sim._steps)
     _lib.check(sim.lib.esim_prof_read(sim._ctx, buf.ctypes.data_as(C.POINTER(C.c_uint32)), buf.size, C.byref(khz)), sim._ctx)
     r = buf.reshape(W, 16).astype(np.int64)
@@ -30,10 +31,11 @@ for target in (96, 192, 960, 1056, 1920, 2880, 3840, 4800, 4896, 4992):
           % (us(r[:, 8].max() - m0), us(r[:, 9].max() - m0), np.median(mt), mt.max(), (r[:, 10] > 0).sum(), r[:, 10].max()))
     b = r[:, 10] > 0
     if b.any():
-        print("        marks stages (waves with entries, median / max us): prologue %.1f/%.1f | word ready %.1f/%.1f | probe %.1f/%.1f | claim %.1f/%.1f | "
-              "wait %.1f/%.1f | counts+pairs %.1f/%.1f | (of probe: before the CAS %.1f/%.1f)" % tuple(x for i in (6, 11, 12, 13, 14, 15, 7) for x in (np.median(us(r[b, i])), us(r[b, i]).max())))
+        print("        marks stages (waves with entries, median / max us): words and keys %.1f/%.1f | hash claims %.1f/%.1f | item records %.1f/%.1f | "
+              "record positions, records %.1f/%.1f | direct counts, route pairs %.1f/%.1f" % tuple(x for i in (11, 12, 13, 14, 15) for x in (np.median(us(r[b, i])), us(r[b, i]).max())))
     big = np.zeros(16384 * 16, np.uint32)
     _lib.check(sim.lib.esim_prof_read(sim._ctx, big.ctypes.data_as(C.POINTER(C.c_uint32)), big.size, C.byref(khz)), sim._ctx)
     bk = big.reshape(16384, 16)[16383].astype(np.int64)
     print("        books (us): count %.1f | finish %.1f | scatter+clean-up %.1f | next (future+decide) %.1f (of which after future %.1f)"
           % tuple(us(bk[i]) for i in (0, 1, 2, 3, 4)))
+    print("        fold, first workgroup (us): counts + scan %.1f | prefix into LDS %.1f | searches + stores %.1f" % tuple(us(bk[i]) for i in (8, 9, 10)))
