@@ -366,7 +366,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if ((rc = dev_alloc(c, &d.item_rec, d.items_cap))) return rc;
         if ((rc = dev_alloc(c, &d.vec, (size_t)cap * FREE_MAX))) return rc;
         if ((rc = dev_alloc(c, &d.slot_state, cap))) return rc;
-        if ((rc = dev_alloc(c, &d.slot_iv, (size_t)cap * 8u))) return rc;
+        if ((rc = dev_alloc(c, &d.slot_iv, (size_t)cap * SLOT_IV_STRIDE))) return rc;
         HIP_TRY(c, hipMemset(d.slot_state, 0, sizeof(uint32_t) * cap));
         // deferred units: SUBQ queues; a queue that is full makes its producer draw the list itself, so the size is a
         // matter of speed only.  Room for the smaller of: every long member list marked in every step; a quarter of the
@@ -391,10 +391,9 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
             d.ovf_room_base = ovf_off.back();
             if ((rc = dev_alloc(c, &d.ovf, (size_t)d.ovf_room_base + room_off.back() + 1u))) return rc;
         }
-        if ((rc = dev_alloc(c, &d.big_list, d.items_cap))) return rc;
-        if ((rc = dev_alloc(c, &d.big_cnt, 16384u))) return rc;
+        d.big_qcap = d.items_cap / SUBQ;             // (a slot is listed at most once a chunk, and there are at most items_cap of them)
+        if ((rc = dev_alloc(c, &d.big_list, (size_t)d.big_qcap * SUBQ * 3u))) return rc;
         if ((rc = dev_alloc(c, &d.used_pref, CHUNK_WAVES_MAX + 1u))) return rc;
-        HIP_TRY(c, hipMemset(d.big_cnt, 0, sizeof(uint32_t) * 16384u));
         if ((rc = dev_alloc(c, &d.pair_cnt, 16384u))) return rc;
         if ((rc = dev_alloc(c, &d.used_cnt, 16384u))) return rc;
         HIP_TRY(c, hipMemset(d.used_cnt, 0, sizeof(uint32_t) * 16384u));

@@ -115,7 +115,12 @@ struct UnitRec { uint32_t slot, link, lo, n_mem, code, own, m_first, pad; };
 struct ItemRec { uint32_t id, a_lo, a_hi, b_lo, b_hi, aux, link, own; };   // link: a room's school item; own: the claimer's interval record
 #define CHUNK_WAVES_MAX 4096u      // wavefronts of a chunk-pass kernel (1024 workgroups of 256)
 #define SLOT_COUNTERS_ONLY 0x40000000u // slot_state of a school building: no interval records, everybody counted in `vec`
-#define ITEM_RECS 7u               // interval records an item holds besides its claimer's
+#ifndef ITEM_RECS
+#define ITEM_RECS 7u               // interval records a slot holds (besides the claimer's, which travels in the item); 15 / 16 measured
+#define SLOT_IV_STRIDE 8u          // 2 % slower on uk64m: the readers' loop over the records costs more than k_chunk_fold saves
+#endif
+#define LANE_STATE 24u             // lanes of a fetched item (fetch_item / fetch_slot): 0..7 its record, 8..8+ITEM_RECS-1 the slot's
+#define LANE_HSLOT 25u             // interval records, then their number and the item's hash slot
 
 // What is in force during one step of a pipelined chunk (k_decide fills dec[0..chunk_ok]).
 struct Decision {
@@ -152,7 +157,7 @@ struct Dev {
     struct ItemRec *item_rec;   // [items_cap] what the draw pass needs of an item, written at claim time
     uint32_t *slot_state;       // [hcap] buildings, rooms: interval records asked for (beyond ITEM_RECS they went into `vec`);
                                 // routes: bit i = the i-th bus step of the chunk has been registered
-    uint32_t *slot_iv;          // [hcap][8] interval records (k_chunk_marks: IV_*)
+    uint32_t *slot_iv;          // [hcap][SLOT_IV_STRIDE] interval records (k_chunk_marks: IV_*)
     uint32_t *vec;              // [hcap][FREE_MAX] per-step counts of the Infected that found no record free
     uint32_t items_cap;
     struct UnitRec *units;      // [SUBQ][unit_qcap] deferred units of long member lists
@@ -166,8 +171,9 @@ struct Dev {
     const uint32_t *ovf_off;    // [n_bld + 1] res_off + wrk_off
     uint32_t ovf_room_base;     // ovf_off[n_bld]
     uint32_t *ovf;              // [ovf_room_base + room_off[n_room]]
-    uint32_t *big_list;         // [items_cap] slots with records in `ovf`, by the wavefront of k_chunk_marks that saw the first
-    uint32_t *big_cnt;          // [wavefronts of k_chunk_marks]
+    uint32_t *big_list;         // [SUBQ][big_qcap][3] slots with records in `ovf`, where those start and how many fit, listed by the first
+                                // to put one there; 64 lists by listing wavefront & 63, lengths in hot[HOT_BIG ...]
+    uint32_t big_qcap;
     uint32_t *used_pref;        // [CHUNK_WAVES_MAX + 1] prefix sums of used_cnt (k_chunk_fold)
     uint32_t unit_qcap;
     uint32_t *newexp;           // [SUBQ][newexp_cap] citizens exposed in the chunk, by id & 63
@@ -237,9 +243,10 @@ struct Dev {
 #define HOT_NEWEXP 0u              // [SUBQ] citizens exposed in the chunk, by citizen id & 63
 #define HOT_UNITS 64u              // [SUBQ] deferred units, by producing wavefront & 63
 #define HOT_BIGPAIRS 128u          // (route, bus step) pairs of routes with more than 64 riders
-#define HOT_PREV_NEWEXP 129u       // [SUBQ] copy of HOT_NEWEXP of the chunk whose log entries k_chunk_scatter is writing
-#define HOT_RESET 129u             // counters k_decide zeroes for a new chunk
-#define HOT_COUNT 193u
+#define HOT_BIG 129u               // [SUBQ] slots listed for k_chunk_fold, by listing wavefront & 63
+#define HOT_PREV_NEWEXP 193u       // [SUBQ] copy of HOT_NEWEXP of the chunk whose log entries k_chunk_scatter is writing
+#define HOT_RESET 193u             // counters k_decide zeroes for a new chunk
+#define HOT_COUNT 257u
 #define UNIT_NOOP 0xFFFFFFFFu
 #define CHUNK_BUS_STEPS 8u         // a one-pass chunk has at most this many steps with riders on a bus
 #define UNIT_PAIRS 256u            // (member, marked step) pairs per deferred unit of a long member list

@@ -527,6 +527,7 @@ __device__ __forceinline__ uint32_t where_in_step(const Dev &d, uint32_t w, uint
     return (q.at_work && (w & FL_HAS_WORK)) ? 2u : 1u;
 }
 
+#define FX(x, i) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (int)(i)))
 // A set of steps of a chunk (FREE_MAX = 96 bits).
 struct M96 { unsigned long long lo; uint32_t hi; };
 __device__ __forceinline__ M96 m96_and(M96 a, M96 b) { return M96{ a.lo & b.lo, a.hi & b.hi }; }
@@ -539,6 +540,29 @@ __device__ __forceinline__ M96 m96_range(uint32_t a, uint32_t b)
     if (a < 64u) { const uint32_t e = min(b, 63u); r.lo = (e == 63u ? ~0ull : ((1ull << (e + 1u)) - 1ull)) & (~0ull << a); }
     if (b >= 64u) { const uint32_t s0 = a > 64u ? a - 64u : 0u, e = min(b - 64u, 31u); r.hi = (e == 31u ? ~0u : ((1u << (e + 1u)) - 1u)) & (~0u << s0); }
     return r;
+}
+
+// The steps of the chunk in which the citizen of interval record iv stands where the record was left (iv_present as a set):
+// AW / BUS = the steps in which those with a work place are at work / riders are on a bus.  With a wavefront-uniform record
+// this is scalar arithmetic; a lane then only picks its step's bit.
+__device__ __forceinline__ M96 iv_steps(uint32_t iv, const M96 &AW, const M96 &BUS)
+{
+    if (!(iv & IV_VALID)) return M96{ 0ull, 0u };
+    const M96 I = m96_range(iv & 127u, (iv >> 7) & 127u);
+    const M96 rest = (iv & IV_PT) ? m96_andn(I, BUS) : I;
+    const M96 atw = (iv & IV_HW) ? m96_and(rest, AW) : M96{ 0ull, 0u };
+    return (iv & IV_AS_WORK) ? atw : m96_andn(rest, atw);
+}
+__device__ __forceinline__ void iv_count(uint32_t iv, uint32_t lane, const M96 &AW, const M96 &BUS, uint32_t &c0, uint32_t &c1)
+{
+    const M96 at = iv_steps(iv, AW, BUS);
+    c0 += (uint32_t)(at.lo >> lane) & 1u;
+    c1 += lane < 32u ? (at.hi >> lane) & 1u : 0u;
+}
+__device__ __forceinline__ void schedule_masks(uint32_t lane, uint32_t n, const Decision &q0, const Decision &q1, M96 &AW, M96 &BUS)
+{
+    AW = M96{ __ballot(lane < n && q0.at_work != 0u), (uint32_t)__ballot(64u + lane < n && q1.at_work != 0u) };
+    BUS = M96{ __ballot(lane < n && q0.bus_dir != 0u), (uint32_t)__ballot(64u + lane < n && q1.bus_dir != 0u) };
 }
 
 // generate_exposures (simulator.rs:181-198) for every step of the chunk: one LANE per citizen that is Infected somewhere in
@@ -580,7 +604,6 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
     const uint32_t pm0 = PROF_NOW();
     uint32_t p_entries = 0u;
     uint32_t my_pairs = 0u;                                                   // (route, bus step) pairs this wavefront registered
-    uint32_t my_big = 0u;                                                     // slots this wavefront listed for k_chunk_fold
     uint32_t ps[5] = { 0u, 0u, 0u, 0u, 0u };                                   // diagnostics: time per stage
     // ONE LANE PER INFECTED CITIZEN: the pass is a chain of dependent round trips (log entry -> word and keys -> hash claim ->
     // the item's lists / a record position -> the record), so what it needs is requests in flight, not lanes per citizen.
@@ -741,24 +764,41 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         // slot's per-step counters, one atomic per step, which nobody has to wait for; so does everybody in a school
         // building); the first to get there lists the slot for k_chunk_fold
         bool direct[3], first[3];
+        uint32_t first_base[3] = { 0u, 0u, 0u }, first_cap[3] = { 0u, 0u, 0u };
 #pragma unroll
         for (uint32_t k = 0; k < 3u; ++k) {
             direct[k] = k == 1u && school && key[1] != HKEY_EMPTY; first[k] = false;
             if (!add_rec[k]) continue;
             const uint32_t iv = k == 0u ? iv_home : iv_work;
-            if (old[k] < ITEM_RECS) { d.slot_iv[(size_t)slot[k] * 8u + old[k]] = iv; continue; }
+            if (old[k] < ITEM_RECS) { d.slot_iv[(size_t)slot[k] * SLOT_IV_STRIDE + old[k]] = iv; continue; }
             const uint32_t q = old[k] - ITEM_RECS, id = (uint32_t)key[k];
             uint32_t base, cap;
             if (k < 2u) { base = d.ovf_off[id]; cap = d.ovf_off[id + 1u] - base; }
             else { const uint32_t r = id - d.n_bld; const uint32_t o = d.room_off[r]; base = d.ovf_room_base + o; cap = d.room_off[r + 1u] - o; }
-            if (q < cap) { d.ovf[base + q] = iv; first[k] = q == 0u; }
+            if (q < cap) { d.ovf[base + q] = iv; first[k] = q == 0u; first_base[k] = base; first_cap[k] = cap; }
             else direct[k] = true;
+        }
+        {
+            // (one reservation in this wavefront's list for everything the 64 citizens list)
+            const unsigned long long f0 = __ballot(first[0]), f1 = __ballot(first[1]), f2 = __ballot(first[2]);
+            const uint32_t n_first = (uint32_t)(__popcll(f0) + __popcll(f1) + __popcll(f2));
+            if (n_first) {
+                const uint32_t r = wave & (SUBQ - 1u);
+                uint32_t at0 = 0u;
+                if (lane == 0) at0 = atomicAdd(&d.hot[(HOT_BIG + r) * HOT_STRIDE], n_first);
+                at0 = __shfl(at0, 0, 64);
+                uint32_t *bl = d.big_list + (size_t)r * d.big_qcap * 3u;
+                uint32_t pos = at0 + (uint32_t)__popcll(f0 & lt);
+                if (first[0] && pos < d.big_qcap) { bl[3u * pos] = slot[0]; bl[3u * pos + 1u] = first_base[0]; bl[3u * pos + 2u] = first_cap[0]; }
+                pos = at0 + (uint32_t)__popcll(f0) + (uint32_t)__popcll(f1 & lt);
+                if (first[1] && pos < d.big_qcap) { bl[3u * pos] = slot[1]; bl[3u * pos + 1u] = first_base[1]; bl[3u * pos + 2u] = first_cap[1]; }
+                pos = at0 + (uint32_t)__popcll(f0) + (uint32_t)__popcll(f1) + (uint32_t)__popcll(f2 & lt);
+                if (first[2] && pos < d.big_qcap) { bl[3u * pos] = slot[2]; bl[3u * pos + 1u] = first_base[2]; bl[3u * pos + 2u] = first_cap[2]; }
+                if (at0 + n_first > d.big_qcap && lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE);
+            }
         }
 #pragma unroll
         for (uint32_t k = 0; k < 3u; ++k) {
-            const unsigned long long fm = __ballot(first[k]);
-            if (first[k]) d.big_list[(size_t)wave * per_wave + my_big + (uint32_t)__popcll(fm & lt)] = slot[k];
-            my_big += (uint32_t)__popcll(fm);
             const M96 at = k == 0u ? ath : atw;
             for (unsigned long long sp = __ballot(direct[k]); sp; sp &= sp - 1ull) {
                 const int src_lane = __builtin_ctzll(sp);
@@ -804,7 +844,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         }
         { const uint32_t pf = PROF_NOW(); ps[0] += pb - pa; ps[1] += pc - pb; ps[2] += pd - pc; ps[3] += pe - pd; ps[4] += pf - pe; }
     }
-    if (lane == 0) { d.pair_cnt[wave] = my_pairs; d.used_cnt[wave] = next_id - wave * per_wave; d.big_cnt[wave] = my_big; }
+    if (lane == 0) { d.pair_cnt[wave] = my_pairs; d.used_cnt[wave] = next_id - wave * per_wave; }
     const uint32_t pm1 = PROF_NOW();
     PROF_PUT(d, 8, pm0); PROF_PUT(d, 9, pm1); PROF_PUT(d, 10, p_entries);
     PROF_PUT(d, 11, ps[0]); PROF_PUT(d, 12, ps[1]); PROF_PUT(d, 13, ps[2]); PROF_PUT(d, 14, ps[3]); PROF_PUT(d, 15, ps[4]);
@@ -850,37 +890,74 @@ __global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
         BOOKS_PROF(d, 8, pf1 - pf0); BOOKS_PROF(d, 9, pf2 - pf1); BOOKS_PROF(d, 10, PROF_NOW() - pf2);
         (void)pf0; (void)pf1; (void)pf2;
     }
-    const uint32_t n_big = min(d.big_cnt[wave], per_wave);
-    if (n_big == 0u) return;
+    // list `wave & 63`, every (n_waves / 64)-th entry of it
+    const uint32_t qr = wave & (SUBQ - 1u), first = wave >> 6, step = n_waves >> 6;
+    const uint32_t n_list = step ? min(ld(&d.hot[(HOT_BIG + qr) * HOT_STRIDE]), d.big_qcap) : 0u;
+#ifdef ESIM_PROFILE_FOLD
+    const uint32_t pq0 = PROF_NOW();
+    uint32_t pq_rec = 0u, pq_n = 0u;
+    PROF_PUT(d, 11, 0u); PROF_PUT(d, 12, 0u); PROF_PUT(d, 13, 0u);
+#endif
+    if (first >= n_list) return;
+    const uint32_t *bl = d.big_list + (size_t)qr * d.big_qcap * 3u;
     const Decision q0 = lane < n ? d.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
     const Decision q1 = 64u + lane < n ? d.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
     const M96 AW = { __ballot(lane < n && q0.at_work != 0u), (uint32_t)__ballot(64u + lane < n && q1.at_work != 0u) };
     const M96 BUS = { __ballot(lane < n && q0.bus_dir != 0u), (uint32_t)__ballot(64u + lane < n && q1.bus_dir != 0u) };
-    for (uint32_t i = 0; i < n_big; ++i) {
-        const uint32_t slot = d.big_list[(size_t)wave * per_wave + i];
-        const uint32_t id = (uint32_t)d.hkey[slot], state = d.slot_state[slot];
-        uint32_t base, cap;
-        if (id < d.n_bld) { base = d.ovf_off[id]; cap = d.ovf_off[id + 1u] - base; }
-        else { const uint32_t r = id - d.n_bld; const uint32_t o = d.room_off[r]; base = d.ovf_room_base + o; cap = d.room_off[r + 1u] - o; }
-        const uint32_t n_ov = min(state > ITEM_RECS ? state - ITEM_RECS : 0u, cap);
-        uint32_t c0 = 0u, c1 = 0u;
-        for (uint32_t b = 0; b < n_ov; b += 64u) {
-            const uint32_t iv = b + lane < n_ov ? d.ovf[base + b + lane] : 0u;
-            // where this record's citizen stands, as in iv_present
-            M96 at = { 0ull, 0u };
-            if (iv & IV_VALID) {
-                const M96 I = m96_range(iv & 127u, (iv >> 7) & 127u);
-                const M96 rest = (iv & IV_PT) ? m96_andn(I, BUS) : I;
-                const M96 atw = (iv & IV_HW) ? m96_and(rest, AW) : M96{ 0ull, 0u };
-                at = (iv & IV_AS_WORK) ? atw : m96_andn(rest, atw);
-            }
-            for (uint32_t j = 0; j < n && j < 64u; ++j) { const uint32_t k = (uint32_t)__popcll(__ballot((at.lo >> j) & 1ull)); if (lane == j) c0 += k; }
-            for (uint32_t j = 64u; j < n; ++j) { const uint32_t k = (uint32_t)__popcll(__ballot((at.hi >> (j - 64u)) & 1u)); if (lane == j - 64u) c1 += k; }
+    for (uint32_t g = first; g < n_list; g += 64u * step) {
+        // 64 of this wavefront's entries at a time, a lane each: the slot, where its records are and how many (those that
+        // did not fit counted themselves)
+        uint32_t slot_l = 0u, base_l = 0u, n_ov_l = 0u;
+        const uint32_t mine = g + lane * step;
+        if (mine < n_list) {
+            slot_l = bl[3u * mine]; base_l = bl[3u * mine + 1u];
+            const uint32_t state = d.slot_state[slot_l];
+            n_ov_l = min((state > ITEM_RECS && state < SLOT_COUNTERS_ONLY) ? state - ITEM_RECS : 0u, bl[3u * mine + 2u]);
         }
-        uint32_t *v = d.vec + (size_t)slot * FREE_MAX;
-        if (lane < n && c0) v[lane] += c0;                                    // (the commuters' atomics of k_chunk_marks are done)
-        if (64u + lane < n && c1) v[64u + lane] += c1;
+        const uint32_t m = min(64u, (n_list - g + step - 1u) / step);
+        // ... then slot by slot, lanes = records; the first 64 records of eight slots are fetched together
+        for (uint32_t i8 = 0; i8 < m; i8 += 8u) {
+        uint32_t ivs[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) ivs[u] = (i8 + u < m && lane < FX(n_ov_l, min(i8 + u, 63u))) ? d.ovf[FX(base_l, min(i8 + u, 63u)) + lane] : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) {
+            const uint32_t i = i8 + u;
+            if (i >= m) break;
+            const uint32_t slot = FX(slot_l, i), base = FX(base_l, i), n_ov = FX(n_ov_l, i);
+            uint32_t iv = ivs[u];
+            uint32_t c0 = 0u, c1 = 0u;
+#ifdef ESIM_PROFILE_FOLD
+            pq_rec += n_ov; ++pq_n;
+#endif
+            for (uint32_t b = 0; b < n_ov; b += 64u) {
+                if (b) iv = b + lane < n_ov ? d.ovf[base + b + lane] : 0u;
+                const uint32_t nb = min(64u, n_ov - b);
+                if (nb <= 12u) {
+                    // few records (a class room): one after the other, its set of steps in scalar registers, lanes = steps
+                    for (uint32_t k = 0; k < nb; ++k) {
+                        const M96 at = iv_steps(FX(iv, k), AW, BUS);
+                        c0 += (uint32_t)(at.lo >> lane) & 1u;
+                        c1 += lane < 32u ? (at.hi >> lane) & 1u : 0u;
+                    }
+                    continue;
+                }
+                // many: lanes = records, one ballot per step
+                const M96 at = iv_steps(iv, AW, BUS);
+                for (uint32_t j = 0; j < n && j < 64u; ++j) { const uint32_t k = (uint32_t)__popcll(__ballot((at.lo >> j) & 1ull)); if (lane == j) c0 += k; }
+                for (uint32_t j = 64u; j < n; ++j) { const uint32_t k = (uint32_t)__popcll(__ballot((at.hi >> (j - 64u)) & 1u)); if (lane == j - 64u) c1 += k; }
+            }
+            uint32_t *v = d.vec + (size_t)slot * FREE_MAX;
+            // (added, not stored: commuters from other shards may have counted themselves there; atomics, because nobody has
+            // to wait for them)
+            if (lane < n && c0) atomicAdd(&v[lane], c0);
+            if (64u + lane < n && c1) atomicAdd(&v[64u + lane], c1);
+        }
+        }
     }
+#ifdef ESIM_PROFILE_FOLD
+    PROF_PUT(d, 11, pq_n); PROF_PUT(d, 12, PROF_NOW() - pq0); PROF_PUT(d, 13, pq_rec);
+#endif
 }
 
 // A successful draw of citizen m in step s (bus: on public transport).
@@ -1002,8 +1079,8 @@ __device__ __forceinline__ uint32_t item_steps_regs(uint32_t c0, uint32_t c1, ui
 }
 
 __device__ __forceinline__ uint32_t fetch_slot(const Dev &d, uint32_t slot, uint32_t lane);
-__device__ __forceinline__ void item_counts(const Dev &d, uint32_t x, uint32_t slot, uint32_t lane, uint32_t n, const Decision &q0,
-                                            const Decision &q1, uint32_t &c0, uint32_t &c1);
+__device__ __forceinline__ void item_counts(const Dev &d, uint32_t x, uint32_t slot, uint32_t lane, uint32_t n, const M96 &AW,
+                                            const M96 &BUS, uint32_t &c0, uint32_t &c1);
 __device__ __forceinline__ void school_counts(const Dev &d, uint32_t s_sch, uint32_t lane, uint32_t n, const Decision &q0, const Decision &q1, WaveScratch &ws)
 {
     // s_sch: the hash slot of the room's school (k_chunk_marks left it in the room's record): infected in the whole school, per
@@ -1053,34 +1130,33 @@ __device__ __forceinline__ void list_or_units(const Dev &d, Ctrl *ctrl, const Ch
 // The fetch of an item is one register in two hops: lanes 0..7 its record and lane 17 its hash slot (ITEM_UNUSED: id not
 // handed out) by item id; then lanes 8..14 the slot's interval records and lane 16 their number by slot.
 struct ItemFetch { uint32_t slot, id, a_lo, a_hi, b_lo, b_hi, aux, link, c0, c1; };
-#define FX(x, i) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (i)))
 __device__ __forceinline__ uint32_t fetch_item(const Dev &d, uint32_t v, uint32_t lane)
 {
     uint32_t x = 0u;
     if (lane < 8u) x = reinterpret_cast<const uint32_t *>(d.item_rec)[(size_t)v * 8u + lane];
-    else if (lane == 17u) x = d.hitems[v];
+    else if (lane == LANE_HSLOT) x = d.hitems[v];
     return x;
 }
 __device__ __forceinline__ uint32_t fetch_slot(const Dev &d, uint32_t slot, uint32_t lane)
 {
     uint32_t x = 0u;
     if (slot != ITEM_UNUSED) {
-        if (lane >= 8u && lane < 8u + ITEM_RECS) x = d.slot_iv[(size_t)slot * 8u + (lane - 8u)];
-        else if (lane == 16u) x = d.slot_state[slot];
+        if (lane >= 8u && lane < 8u + ITEM_RECS) x = d.slot_iv[(size_t)slot * SLOT_IV_STRIDE + (lane - 8u)];
+        else if (lane == LANE_STATE) x = d.slot_state[slot];
     }
     return x;
 }
 __device__ __forceinline__ uint32_t merge_fetch(uint32_t by_id, uint32_t by_slot, uint32_t lane)
 {
-    return (lane < 8u || lane == 17u) ? by_id : by_slot;
+    return (lane < 8u || lane == LANE_HSLOT) ? by_id : by_slot;
 }
 
 // Infected standing in the item in step `lane` (c0) and `64 + lane` (c1) of the chunk: the records of its slot, plus the
 // per-step counters of those that found no record free.  (The claimer's own stretch is added by decode_item.)
-__device__ __forceinline__ void item_counts(const Dev &d, uint32_t x, uint32_t slot, uint32_t lane, uint32_t n, const Decision &q0,
-                                            const Decision &q1, uint32_t &c0, uint32_t &c1)
+__device__ __forceinline__ void item_counts(const Dev &d, uint32_t x, uint32_t slot, uint32_t lane, uint32_t n, const M96 &AW,
+                                            const M96 &BUS, uint32_t &c0, uint32_t &c1)
 {
-    const uint32_t state = FX(x, 16);
+    const uint32_t state = FX(x, LANE_STATE);
     c0 = 0u; c1 = 0u;
     if (state > ITEM_RECS) {
         // (summed up by k_chunk_fold from the records beyond ITEM_RECS)
@@ -1090,21 +1166,18 @@ __device__ __forceinline__ void item_counts(const Dev &d, uint32_t x, uint32_t s
     const uint32_t n_rec = state >= SLOT_COUNTERS_ONLY ? 0u : state < ITEM_RECS ? state : ITEM_RECS;
     for (uint32_t k = 0; k < n_rec; ++k) {
         const uint32_t iv = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)(8u + k));
-        if (lane < n) c0 += iv_present(iv, lane, q0);
-        if (64u + lane < n) c1 += iv_present(iv, 64u + lane, q1);
+        iv_count(iv, lane, AW, BUS, c0, c1);
     }
 }
 
-__device__ __forceinline__ ItemFetch decode_item(const Dev &d, uint32_t x, uint32_t lane, uint32_t n, const Decision &q0, const Decision &q1)
+__device__ __forceinline__ ItemFetch decode_item(const Dev &d, uint32_t x, uint32_t lane, uint32_t n, const M96 &AW, const M96 &BUS)
 {
     ItemFetch f;
-    f.slot = FX(x, 17); f.id = FX(x, 0); f.a_lo = FX(x, 1); f.a_hi = FX(x, 2); f.b_lo = FX(x, 3); f.b_hi = FX(x, 4); f.aux = FX(x, 5); f.link = FX(x, 6);
+    f.slot = FX(x, LANE_HSLOT); f.id = FX(x, 0); f.a_lo = FX(x, 1); f.a_hi = FX(x, 2); f.b_lo = FX(x, 3); f.b_hi = FX(x, 4); f.aux = FX(x, 5); f.link = FX(x, 6);
     f.c0 = 0u; f.c1 = 0u;
     if (f.slot != ITEM_UNUSED) {
-        item_counts(d, x, f.slot, lane, n, q0, q1, f.c0, f.c1);
-        const uint32_t own = FX(x, 7);
-        if (lane < n) f.c0 += iv_present(own, lane, q0);
-        if (64u + lane < n) f.c1 += iv_present(own, 64u + lane, q1);
+        item_counts(d, x, f.slot, lane, n, AW, BUS, f.c0, f.c1);
+        iv_count(FX(x, 7), lane, AW, BUS, f.c0, f.c1);
     }
     return f;
 }
@@ -1168,7 +1241,9 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     WaveScratch &ws = wsc[threadIdx.x >> 6];
     const Decision q0 = lane < n ? sm.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
     const Decision q1 = 64u + lane < n ? sm.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
-    if (d_lo < d_hi) sl_cur = fetch_slot(d, FX(id_cur, 17), lane);
+    M96 AW, BUS;
+    schedule_masks(lane, n, q0, q1, AW, BUS);
+    if (d_lo < d_hi) sl_cur = fetch_slot(d, FX(id_cur, LANE_HSLOT), lane);
     if (have) { const uint32_t r = code_l >> 7; off_l = d.route_off[r]; sz_l = d.route_off[r + 1] - off_l; }
     const uint32_t pt1 = PROF_NOW();
     // (1) buildings and school rooms: one wavefront per item
@@ -1176,8 +1251,8 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
         const uint32_t x = merge_fetch(id_cur, sl_cur, lane);
         id_cur = id_nxt;
         if (v + 2u < d_hi) id_nxt = fetch_item(d, id_of(v + 2u), lane);
-        if (v + 1u < d_hi) sl_cur = fetch_slot(d, FX(id_cur, 17), lane);
-        const ItemFetch it = decode_item(d, x, lane, n, q0, q1);
+        if (v + 1u < d_hi) sl_cur = fetch_slot(d, FX(id_cur, LANE_HSLOT), lane);
+        const ItemFetch it = decode_item(d, x, lane, n, AW, BUS);
         if (it.slot == ITEM_UNUSED) continue;
         if (it.id >= route_base) continue;
         const uint32_t pi0 = PROF_NOW();
@@ -1302,6 +1377,8 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
     const uint32_t *q_words = reinterpret_cast<const uint32_t *>(d.units + (size_t)qr * d.unit_qcap);
     const Decision q0 = lane < n ? sm.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
     const Decision q1 = 64u + lane < n ? sm.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
+    M96 AW, BUS;
+    schedule_masks(lane, n, q0, q1, AW, BUS);
     // Per unit: its record (lanes 0..7 of one register); then, together, the slot's interval records, the school's, and the
     // ids of the first members its pairs touch; then those members' words.  The record of the unit after next and the
     // second stage of the next are in flight while this one draws.
@@ -1331,12 +1408,11 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
         const uint32_t kind = code >> 30, p_lo = code & 0x3FFFFFFFu, slot = FX(u, 0), link = FX(u, 1), lo = FX(u, 2), n_mem = FX(u, 3), own = FX(u, 5), mf = FX(u, 6);
         const uint32_t mw = (mf + lane < n_mem) ? d.cit[mid] : 0u;
         uint32_t c0, c1;
-        item_counts(d, xs, slot, lane, n, q0, q1, c0, c1);
-        if (lane < n) c0 += iv_present(own, lane, q0);
-        if (64u + lane < n) c1 += iv_present(own, 64u + lane, q1);
+        item_counts(d, xs, slot, lane, n, AW, BUS, c0, c1);
+        iv_count(own, lane, AW, BUS, c0, c1);
         if (kind == 2u) {
             uint32_t s0 = 0u, s1 = 0u;
-            if (link != 0xFFFFFFFFu) item_counts(d, ys, link, lane, n, q0, q1, s0, s1);
+            if (link != 0xFFFFFFFFu) item_counts(d, ys, link, lane, n, AW, BUS, s0, s1);
             ws.sch[lane] = s0;
             if (lane < FREE_MAX - 64u) ws.sch[64u + lane] = s1;
         }
