@@ -981,7 +981,10 @@ struct RouteShared {
     uint8_t s_inf[CHUNK_ROUTE_MAX];
     uint32_t s_cnt[CHUNK_ROUTE_MAX + 1];
 };
-struct WaveScratch { uint32_t cnt[FREE_MAX]; uint32_t sch[FREE_MAX]; uint32_t mem_id[64]; uint32_t mem_w[64]; uint8_t steps[FREE_MAX]; uint8_t mk[FREE_MAX]; };
+// Per wavefront: the item's / the school's Infected per step; 64 staged members; the item's step-pair slots (item_steps_regs).
+// A slot's descriptor is four words, two per step (even time step first): word A = step of the chunk (bits 0-6) | marked (7) |
+// at work (8) | masks everywhere (9) | the school's Infected & 255 (10-17), word B = the item's Infected in that step.
+struct WaveScratch { uint32_t cnt[FREE_MAX]; uint32_t sch[FREE_MAX]; uint32_t mem_id[64]; uint32_t mem_w[64]; uint4 desc[FREE_MAX / 2u + 1u]; };
 
 // One member list of one item over the marked steps of the chunk.  Two consecutive time steps 2k, 2k+1 share one Philox block
 // (RNG contract: the even step takes words 0-1, the odd one words 2-3), so the unit of work is a (member, step PAIR) slot: the
@@ -1014,28 +1017,25 @@ __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const Chu
             const uint32_t m = ws.mem_id[um - mb], w = ws.mem_w[um - mb];
             const uint32_t te = CW_TE(w);
             if (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) continue;
-            const uint32_t jj = ws.steps[si], mk = ws.mk[si];                 // the slot's steps are jj - 1 (even time step) and jj (odd)
-            const uint32_t vrel = CW_VAX_REL(w);
+            const uint4 dsc = ws.desc[si];
+            const uint32_t vrel = CW_VAX_REL(w), keep = w & CW_KEEP;
+            const bool same = w & FL_SAME_AREA, hw = w & FL_HAS_WORK, lax = !(w & FL_MASK_COMPLIANT);
             bool act[2]; uint64_t thr[2]; uint32_t cnt[2];
 #pragma unroll
             for (uint32_t h = 0; h < 2u; ++h) {
-                act[h] = false; thr[h] = 0ull; cnt[h] = 0u;
-                if (!((mk >> h) & 1u)) continue;
-                const uint32_t j = jj - 1u + h, s = t0 + j;
-                // Susceptible when this list is walked in step s: never exposed, or so far only exposed by something that
-                // comes later (a later step, or a bus of this step) -- that exposure may be undercut
-                if (w <= CW_MAKE(s + TE_BIAS, w & CW_KEEP)) continue;
-                if (j > vrel) continue;                                                     // Vaccinated by then (k_chunk_vax)
-                const uint32_t at_work = sm.dec[j].at_work, mask = sm.dec[j].mask;
-                const bool same = w & FL_SAME_AREA;
-                if (kind == 0u) { if (at_work && (w & FL_HAS_WORK) && !same) continue; }   // simulator.rs:324
-                else if (!at_work && !same) continue;
-                cnt[h] = ws.cnt[j];
-                const uint32_t nn = kind == 2u ? ws.sch[j] : cnt[h];                        // exposure_count: infected in the building
-                const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
-                thr[h] = sm.thr[row * 256u + (nn & 255u)];
-                act[h] = true;
+                const uint32_t A = h ? dsc.z : dsc.x;
+                cnt[h] = h ? dsc.w : dsc.y;
+                const uint32_t j = A & 127u;
+                const bool atw = (A >> 8) & 1u;
+                // marked; Susceptible when this list is walked in that step (never exposed, or so far only by something that
+                // comes later -- a later step, or a bus of this step: that exposure may be undercut); not Vaccinated by then
+                // (k_chunk_vax); standing in the building's area (simulator.rs:324)
+                act[h] = ((A >> 7) & 1u) && w > (((t0 + j + TE_BIAS) << 19) | keep) && j <= vrel &&
+                         (kind == 0u ? !(atw && hw && !same) : (atw || same));
+                const uint32_t nn = kind == 2u ? (A >> 10) & 255u : cnt[h] & 255u;          // exposure_count: infected in the building
+                thr[h] = sm.thr[((lax && ((A >> 9) & 1u)) ? 256u : 0u) + nn];
             }
+            const uint32_t jj = (dsc.z & 127u);                               // the slot's odd time step (its even one is jj - 1)
             if (!act[0] && !act[1]) continue;
             const uint32_t gid = d.id_base + m;
             const uint32_t s_blk = t0 + jj - (act[0] ? 1u : 0u);              // any step of the slot names its block
@@ -1059,22 +1059,31 @@ __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const Chu
     }
 }
 
-// The marked steps of item v as (even, odd) time-step slots, in order, and its per-step counts, into this wavefront's scratch.
-// Returns S, the number of slots with a marked step.
-__device__ __forceinline__ uint32_t item_steps_regs(uint32_t c0, uint32_t c1, uint32_t lane, WaveScratch &ws, uint32_t t0)
+// The marked steps of item v as (even, odd) time-step slots, in order, with what member_pairs needs of each step, into this
+// wavefront's scratch (ws.sch holds the school's counts when the item is a room).  Returns S, the number of slots with a marked step.
+__device__ __forceinline__ uint32_t item_steps_regs(uint32_t c0, uint32_t c1, uint32_t lane, WaveScratch &ws, uint32_t t0, const ChunkShared &sm)
 {
     ws.cnt[lane] = c0;
     if (lane < FREE_MAX - 64u) ws.cnt[64u + lane] = c1;
     const unsigned long long b0 = __ballot(c0 != 0u), b1 = __ballot(c1 != 0u);
+    __builtin_amdgcn_wave_barrier();
     // lane L looks at the slot whose even time step is step je = 2L - (t0 & 1) of the chunk (je = -1: only its odd step 0 exists)
     const int je = 2 * (int)lane - (int)(t0 & 1u);
     auto marked = [&](int j) -> uint32_t {
         if (j < 0 || j >= (int)FREE_MAX) return 0u;
         return (uint32_t)(((j < 64 ? b0 >> j : b1 >> (j - 64))) & 1ull);
     };
-    const uint32_t mk = lane <= (FREE_MAX + 1u) / 2u ? (marked(je) | (marked(je + 1) << 1)) : 0u;
-    const unsigned long long present = __ballot(mk != 0u);
-    if (mk) { const uint32_t i = (uint32_t)__popcll(present & ((1ull << lane) - 1ull)); ws.steps[i] = (uint8_t)(je + 1); ws.mk[i] = (uint8_t)mk; }
+    const uint32_t m0 = lane <= (FREE_MAX + 1u) / 2u ? marked(je) : 0u, m1 = lane <= (FREE_MAX + 1u) / 2u ? marked(je + 1) : 0u;
+    const unsigned long long present = __ballot((m0 | m1) != 0u);
+    if (m0 | m1) {
+        auto word_a = [&](int j, uint32_t m) -> uint32_t {
+            const uint32_t jc = (uint32_t)(j < 0 ? 0 : j >= (int)FREE_MAX ? (int)FREE_MAX - 1 : j);
+            const Decision &q = sm.dec[jc];
+            return ((uint32_t)j & 127u) | (m << 7) | ((q.at_work ? 1u : 0u) << 8) | ((q.mask == ESIM_MASK_EVERYWHERE ? 1u : 0u) << 9) | ((ws.sch[jc] & 255u) << 10);
+        };
+        const uint32_t i = (uint32_t)__popcll(present & ((1ull << lane) - 1ull));
+        ws.desc[i] = make_uint4(word_a(je, m0), m0 ? ws.cnt[je] : 0u, word_a(je + 1, m1), m1 ? ws.cnt[je + 1] : 0u);
+    }
     return (uint32_t)__popcll(present);
 }
 
@@ -1266,7 +1275,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
             if (lane < n_wrk) wm = d.wrk_idx[it.b_lo + lane];
             if (lane < n_res) rw = d.cit[rm];
             if (lane < n_wrk) ww = d.cit[wm];
-            const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws, t0);
+            const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws, t0, sm);
             __builtin_amdgcn_wave_barrier();
             // Household / Workplace::find_exposures: every registered occupant (building.rs:202-204,278-280)
             const UnitSrc src = { it.slot, it.link, FX(x, 7) };
@@ -1278,7 +1287,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
             if (lane < n_mem) mm = d.room_idx[it.a_lo + lane];
             school_counts(d, it.link, lane, n, q0, q1, ws);
             if (lane < n_mem) mw = d.cit[mm];
-            const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws, t0);
+            const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws, t0, sm);
             __builtin_amdgcn_wave_barrier();
             // School::find_exposures: the room once per infected in it (building.rs:494-522)
             const UnitSrc src = { it.slot, it.link, FX(x, 7) };
@@ -1417,7 +1426,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
             if (lane < FREE_MAX - 64u) ws.sch[64u + lane] = s1;
         }
         const uint32_t *idx = kind == 2u ? d.room_idx : kind == 1u ? d.wrk_idx : d.res_idx;
-        const uint32_t S = item_steps_regs(c0, c1, lane, ws, t0);
+        const uint32_t S = item_steps_regs(c0, c1, lane, ws, t0, sm);
         __builtin_amdgcn_wave_barrier();
         const uint32_t pairs = n_mem * S;
         member_pairs(d, ctrl, sm, ws, idx, lo, p_lo, min(pairs, p_lo + UNIT_PAIRS), lane, kind, S, t0, true, mid, mw, mf);
