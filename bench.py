@@ -70,6 +70,11 @@ def timed_run(sim, steps):
                  "chunks_cut": kv["cuts"], "k_pipe_steps": kp["steps"], "sequential_steps": seq_steps,
                  "steps_with_vaccination_active": int((rec["vaccination_active"] > 0).sum()), "steps_in_lockdown": int((rec["lockdown"] > 0).sum()),
                  "peak_infected": int(rec["infected"].max()),
+                 # what the sparse pass actually works on: one (Infected citizen, step) makes the draws of that citizen's buildings
+                 # in that step.  The epidemic is one random realisation -- its size moves the wall time, not the code's speed.
+                 "infected_citizen_steps": int(rec["infected"].astype("int64").sum()),
+                 "exposures": int(rec["exposures_building"].astype("int64").sum() + rec["exposures_bus"].astype("int64").sum()),
+                 "device_ns_per_infected_citizen_step": device_ms * 1e6 / max(1, int(rec["infected"].astype("int64").sum())),
                  "final_record": {k: int(rec[k][-1]) for k in ("time_step",) + CENSUS}}
 
 

@@ -136,8 +136,8 @@ extern "C" void esim_default_params(esim_params *p)
     p->max_steps = 5000;                                                   // disease.rs:124
 }
 
-// ceil(q * 2^53): `uniform < q` (citizen.rs:242) for uniform = u53 * 2^-53 is exactly
-// `u53 < ceil(q * 2^53)`, because scaling a double by 2^53 is exact.
+// ceil(q * 2^32): `uniform < q` (citizen.rs:242) for uniform = w * 2^-32 (w a 32-bit word) is exactly
+// `w < ceil(q * 2^32)`, because scaling a double by 2^32 is exact.
 extern "C" int esim_threshold_lut(const esim_params *p, uint64_t out[512])
 {
     if (!p || !out) return ESIM_EINVAL;
@@ -148,7 +148,7 @@ extern "C" int esim_threshold_lut(const esim_params *p, uint64_t out[512])
         if (std::signbit(chance)) chance = 0.0;
         for (int n = 0; n < 256; ++n) {
             const double q = 1.0 - std::pow(1.0 - chance, (double)n);      // binomial, citizen.rs:47-49
-            const double scaled = std::ceil(std::ldexp(q, 53));
+            const double scaled = std::ceil(std::ldexp(q, 32));
             out[row * 256 + n] = scaled <= 0.0 ? 0ull : (uint64_t)scaled;
         }
     }

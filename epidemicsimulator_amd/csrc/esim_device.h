@@ -191,7 +191,7 @@ struct Dev {
     uint32_t *hist;             // [TE_SLOTS] citizens per exposure time (census without a pass over citizens)
     uint32_t *log;              // exposure log: citizen ids in order of exposure step
     uint32_t *log_off;          // [TE_SLOTS + 1] first log entry whose te >= k
-    const uint64_t *thr;        // [2][256] ceil(q * 2^53)
+    const uint64_t *thr;        // [2][256] ceil(q * 2^32)
     Ctrl *ctrl;
     struct esim_step_result *records;   // [max_steps + 1]
     // public transport: static route lists (riders of a route share (home area, work area))

@@ -20,7 +20,7 @@
 //    step t" is one contiguous slice of that log;
 //  * where citizens stand is global (same working hours for everybody, citizen.rs:154-155).
 // All draws are Philox4x32-10 keyed (global citizen, step, slot); probabilities are integer
-// thresholds ceil(q*2^53) from a host-built LUT, so every comparison is exact integer work.
+// thresholds ceil(q*2^32) from a host-built LUT, so every comparison is exact integer work.
 #include "esim_kernels_common.h"
 #include "esim_kernels_step.h"
 #include "esim_kernels_chunk.h"

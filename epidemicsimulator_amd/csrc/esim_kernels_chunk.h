@@ -981,16 +981,17 @@ struct RouteShared {
     uint8_t s_inf[CHUNK_ROUTE_MAX];
     uint32_t s_cnt[CHUNK_ROUTE_MAX + 1];
 };
-// Per wavefront: the item's / the school's Infected per step; 64 staged members; the item's step-pair slots (item_steps_regs).
-// A slot's descriptor is four words, two per step (even time step first): word A = step of the chunk (bits 0-6) | marked (7) |
-// at work (8) | masks everywhere (9) | the school's Infected & 255 (10-17), word B = the item's Infected in that step.
-struct WaveScratch { uint32_t cnt[FREE_MAX]; uint32_t sch[FREE_MAX]; uint32_t mem_id[64]; uint32_t mem_w[64]; uint4 desc[FREE_MAX / 2u + 1u]; };
+// Per wavefront: the item's / the school's Infected per step; 64 staged members; the item's slots of four time steps
+// (item_steps_regs).  A slot's descriptor is eight words, two per step (time step 4k first): word A = step of the chunk
+// (bits 0-6) | marked (7) | at work (8) | masks everywhere (9) | the school's Infected & 255 (10-17), word B = the item's
+// Infected in that step.
+#define SLOT_STEPS 4u
+struct WaveScratch { uint32_t cnt[FREE_MAX]; uint32_t sch[FREE_MAX]; uint32_t mem_id[64]; uint32_t mem_w[64]; uint4 desc[2u * (FREE_MAX / SLOT_STEPS + 1u)]; };
 
-// One member list of one item over the marked steps of the chunk.  Two consecutive time steps 2k, 2k+1 share one Philox block
-// (RNG contract: the even step takes words 0-1, the odd one words 2-3), so the unit of work is a (member, step PAIR) slot: the
-// slots [p_lo, p_hi) are spread densely over the 64 lanes (the draws are Philox-bound -- 20 quarter-rate multiplies a block --
-// so idle lanes and blocks used for one draw only are what costs).  ws.steps / ws.mk: the item's slots in order (first step of the
-// slot + 1, which of its two steps are marked), S of them; ws.cnt / ws.sch: the item's / the school's Infected per step.
+// One member list of one item over the marked steps of the chunk.  The time steps 4k .. 4k+3 share one Philox block (RNG
+// contract: step t takes word t & 3), so the unit of work is a (member, slot of four steps) pair: the pairs [p_lo, p_hi) are
+// spread densely over the 64 lanes (the draws are Philox-bound -- 20 quarter-rate multiplies a block -- so idle lanes and
+// blocks used for one draw only are what costs).  ws.desc: the item's slots with a marked step, in order, S of them.
 // kind 0 residents, 1 workers, 2 room participants.
 // pre_m / pre_w: members lo + pre_base + lane of the list and their words when the caller has already fetched them (have_pre).
 __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, WaveScratch &ws, const uint32_t *idx,
@@ -1017,72 +1018,81 @@ __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const Chu
             const uint32_t m = ws.mem_id[um - mb], w = ws.mem_w[um - mb];
             const uint32_t te = CW_TE(w);
             if (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) continue;
-            const uint4 dsc = ws.desc[si];
+            const uint4 dsc0 = ws.desc[2u * si], dsc1 = ws.desc[2u * si + 1u];
+            const uint32_t A[SLOT_STEPS] = { dsc0.x, dsc0.z, dsc1.x, dsc1.z }, cnt[SLOT_STEPS] = { dsc0.y, dsc0.w, dsc1.y, dsc1.w };
             const uint32_t vrel = CW_VAX_REL(w), keep = w & CW_KEEP;
             const bool same = w & FL_SAME_AREA, hw = w & FL_HAS_WORK, lax = !(w & FL_MASK_COMPLIANT);
-            bool act[2]; uint64_t thr[2]; uint32_t cnt[2];
+            bool act[SLOT_STEPS]; uint64_t thr[SLOT_STEPS];
+            bool any = false;
+            uint32_t s_blk = 0u;                                              // a time step of the slot: names its block
 #pragma unroll
-            for (uint32_t h = 0; h < 2u; ++h) {
-                const uint32_t A = h ? dsc.z : dsc.x;
-                cnt[h] = h ? dsc.w : dsc.y;
-                const uint32_t j = A & 127u;
-                const bool atw = (A >> 8) & 1u;
+            for (uint32_t h = 0; h < SLOT_STEPS; ++h) {
+                const uint32_t j = A[h] & 127u;
+                const bool atw = (A[h] >> 8) & 1u;
                 // marked; Susceptible when this list is walked in that step (never exposed, or so far only by something that
                 // comes later -- a later step, or a bus of this step: that exposure may be undercut); not Vaccinated by then
                 // (k_chunk_vax); standing in the building's area (simulator.rs:324)
-                act[h] = ((A >> 7) & 1u) && w > (((t0 + j + TE_BIAS) << 19) | keep) && j <= vrel &&
+                act[h] = ((A[h] >> 7) & 1u) && w > (((t0 + j + TE_BIAS) << 19) | keep) && j <= vrel &&
                          (kind == 0u ? !(atw && hw && !same) : (atw || same));
-                const uint32_t nn = kind == 2u ? (A >> 10) & 255u : cnt[h] & 255u;          // exposure_count: infected in the building
-                thr[h] = sm.thr[((lax && ((A >> 9) & 1u)) ? 256u : 0u) + nn];
+                const uint32_t nn = kind == 2u ? (A[h] >> 10) & 255u : cnt[h] & 255u;       // exposure_count: infected in the building
+                thr[h] = sm.thr[((lax && ((A[h] >> 9) & 1u)) ? 256u : 0u) + nn];
+                if (act[h]) { any = true; s_blk = t0 + j; }
             }
-            const uint32_t jj = (dsc.z & 127u);                               // the slot's odd time step (its even one is jj - 1)
-            if (!act[0] && !act[1]) continue;
+            if (!any) continue;
             const uint32_t gid = d.id_base + m;
-            const uint32_t s_blk = t0 + jj - (act[0] ? 1u : 0u);              // any step of the slot names its block
-            bool hit0 = false, hit1 = false;
+            uint32_t hit = 0u;                                                // bit h: a draw of step h succeeded
             if (kind == 2u) {
-                // School::find_exposures: one draw per Infected in the room (building.rs:494-522)
-                const uint32_t kmax = max(act[0] ? cnt[0] : 0u, act[1] ? cnt[1] : 0u);
-                for (uint32_t k = 0; k < kmax && !hit0; ++k) {
+                // School::find_exposures: one draw per Infected in the room (building.rs:494-522); the earliest step decides
+                uint32_t kmax = 0u, first_act = SLOT_STEPS;
+#pragma unroll
+                for (uint32_t h = SLOT_STEPS; h-- > 0u;) if (act[h]) { kmax = max(kmax, cnt[h]); first_act = h; }
+                for (uint32_t k = 0; k < kmax && !((hit >> first_act) & 1u); ++k) {
                     const philox_out o = esim_draw_block(seed, gid, s_blk, ESIM_SLOT_ROOM0 + k);
-                    if (act[0] && k < cnt[0]) hit0 = ((((uint64_t)o.w0 << 32) | o.w1) >> 11) < thr[0];
-                    if (act[1] && k < cnt[1] && !hit1) hit1 = ((((uint64_t)o.w2 << 32) | o.w3) >> 11) < thr[1];
+                    const uint32_t wd[SLOT_STEPS] = { o.w0, o.w1, o.w2, o.w3 };
+#pragma unroll
+                    for (uint32_t h = 0; h < SLOT_STEPS; ++h) if (act[h] && k < cnt[h] && (uint64_t)wd[h] < thr[h]) hit |= 1u << h;
                 }
             } else {
                 const philox_out o = esim_draw_block(seed, gid, s_blk, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK);
-                hit0 = act[0] && ((((uint64_t)o.w0 << 32) | o.w1) >> 11) < thr[0];
-                hit1 = act[1] && ((((uint64_t)o.w2 << 32) | o.w3) >> 11) < thr[1];
+                const uint32_t wd[SLOT_STEPS] = { o.w0, o.w1, o.w2, o.w3 };
+#pragma unroll
+                for (uint32_t h = 0; h < SLOT_STEPS; ++h) if (act[h] && (uint64_t)wd[h] < thr[h]) hit |= 1u << h;
             }
-            if (hit0) expose_min(d, ctrl, m, w, t0 + jj - 1u, 0u);             // (the earlier of the two wins anyway)
-            else if (hit1) expose_min(d, ctrl, m, w, t0 + jj, 0u);
+            if (hit) expose_min(d, ctrl, m, w, t0 + (((hit & 1u) ? A[0] : (hit & 2u) ? A[1] : (hit & 4u) ? A[2] : A[3]) & 127u), 0u);   // (the earliest wins anyway)
         }
     }
 }
 
-// The marked steps of item v as (even, odd) time-step slots, in order, with what member_pairs needs of each step, into this
-// wavefront's scratch (ws.sch holds the school's counts when the item is a room).  Returns S, the number of slots with a marked step.
+// The marked steps of item v as slots of four time steps (4k .. 4k+3), in order, with what member_pairs needs of each step,
+// into this wavefront's scratch (ws.sch holds the school's counts when the item is a room).  Returns S, the number of slots
+// with a marked step.
 __device__ __forceinline__ uint32_t item_steps_regs(uint32_t c0, uint32_t c1, uint32_t lane, WaveScratch &ws, uint32_t t0, const ChunkShared &sm)
 {
     ws.cnt[lane] = c0;
     if (lane < FREE_MAX - 64u) ws.cnt[64u + lane] = c1;
     const unsigned long long b0 = __ballot(c0 != 0u), b1 = __ballot(c1 != 0u);
     __builtin_amdgcn_wave_barrier();
-    // lane L looks at the slot whose even time step is step je = 2L - (t0 & 1) of the chunk (je = -1: only its odd step 0 exists)
-    const int je = 2 * (int)lane - (int)(t0 & 1u);
+    // lane L looks at the slot whose first time step is step j0 = 4L - (t0 & 3) of the chunk (negative: before the chunk)
+    const int j0 = (int)(SLOT_STEPS * lane) - (int)(t0 & (SLOT_STEPS - 1u));
     auto marked = [&](int j) -> uint32_t {
         if (j < 0 || j >= (int)FREE_MAX) return 0u;
         return (uint32_t)(((j < 64 ? b0 >> j : b1 >> (j - 64))) & 1ull);
     };
-    const uint32_t m0 = lane <= (FREE_MAX + 1u) / 2u ? marked(je) : 0u, m1 = lane <= (FREE_MAX + 1u) / 2u ? marked(je + 1) : 0u;
-    const unsigned long long present = __ballot((m0 | m1) != 0u);
-    if (m0 | m1) {
+    uint32_t mk[SLOT_STEPS];
+    uint32_t any = 0u;
+#pragma unroll
+    for (uint32_t h = 0; h < SLOT_STEPS; ++h) { mk[h] = lane <= FREE_MAX / SLOT_STEPS ? marked(j0 + (int)h) : 0u; any |= mk[h]; }
+    const unsigned long long present = __ballot(any != 0u);
+    if (any) {
         auto word_a = [&](int j, uint32_t m) -> uint32_t {
             const uint32_t jc = (uint32_t)(j < 0 ? 0 : j >= (int)FREE_MAX ? (int)FREE_MAX - 1 : j);
             const Decision &q = sm.dec[jc];
             return ((uint32_t)j & 127u) | (m << 7) | ((q.at_work ? 1u : 0u) << 8) | ((q.mask == ESIM_MASK_EVERYWHERE ? 1u : 0u) << 9) | ((ws.sch[jc] & 255u) << 10);
         };
+        auto word_b = [&](int j, uint32_t m) -> uint32_t { return m ? ws.cnt[j] : 0u; };
         const uint32_t i = (uint32_t)__popcll(present & ((1ull << lane) - 1ull));
-        ws.desc[i] = make_uint4(word_a(je, m0), m0 ? ws.cnt[je] : 0u, word_a(je + 1, m1), m1 ? ws.cnt[je + 1] : 0u);
+        ws.desc[2u * i] = make_uint4(word_a(j0, mk[0]), word_b(j0, mk[0]), word_a(j0 + 1, mk[1]), word_b(j0 + 1, mk[1]));
+        ws.desc[2u * i + 1u] = make_uint4(word_a(j0 + 2, mk[2]), word_b(j0 + 2, mk[2]), word_a(j0 + 3, mk[3]), word_b(j0 + 3, mk[3]));
     }
     return (uint32_t)__popcll(present);
 }
@@ -1347,7 +1357,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
             const uint32_t te = CW_TE(w);
             if (!(w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_KEEP)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) || j > CW_VAX_REL(w))) {   // not exposed before this bus, not Vaccinated by then
                 const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
-                if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
+                if (esim_u32(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
             }
         }
         }
@@ -1466,7 +1476,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
             const uint32_t w = d.cit[c], te = CW_TE(w);
             if (w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_KEEP)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) || j > CW_VAX_REL(w)) continue;   // exposed before this bus, or Vaccinated by then
             const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
-            if (esim_u53(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
+            if (esim_u32(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
         }
         __syncthreads();
     }

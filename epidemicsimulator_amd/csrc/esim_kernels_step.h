@@ -83,7 +83,7 @@ __device__ __forceinline__ bool building_draws(const Dev &d, uint32_t c, uint32_
     // "If the Citizen is not currently in the Area, they haven't been exposed!" simulator.rs:324
     if (!atw || same) {
         const uint32_t n = cnt_bld[d.home[c]];
-        if (n && esim_u53(seed, g, t, ESIM_SLOT_HOME) < threshold(d, fl, mask, n)) return true;
+        if (n && esim_u32(seed, g, t, ESIM_SLOT_HOME) < threshold(d, fl, mask, n)) return true;
     }
     if ((fl & FL_HAS_WORK) && (at_work || same)) {
         const uint32_t n = cnt_bld[d.work[c]];
@@ -92,8 +92,8 @@ __device__ __forceinline__ bool building_draws(const Dev &d, uint32_t c, uint32_
             if (fl & FL_WORK_SCHOOL) {
                 const uint32_t k = cnt_room[d.room[c]];                 // one copy of the room per infected
                 for (uint32_t j = 0; j < k; ++j)
-                    if (esim_u53(seed, g, t, ESIM_SLOT_ROOM0 + j) < thr) return true;
-            } else if (esim_u53(seed, g, t, ESIM_SLOT_WORK) < thr) return true;
+                    if (esim_u32(seed, g, t, ESIM_SLOT_ROOM0 + j) < thr) return true;
+            } else if (esim_u32(seed, g, t, ESIM_SLOT_WORK) < thr) return true;
         }
     }
     return false;
@@ -113,8 +113,8 @@ __device__ __forceinline__ void member_eval(const Dev &d, Ctrl *ctrl, uint32_t m
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
     const uint32_t g = d.id_base + m;
     bool hit = false;
-    if (kind == 2u) { for (uint32_t j = 0; j < k && !hit; ++j) hit = esim_u53(seed, g, t, ESIM_SLOT_ROOM0 + j) < thr; }
-    else hit = esim_u53(seed, g, t, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK) < thr;
+    if (kind == 2u) { for (uint32_t j = 0; j < k && !hit; ++j) hit = esim_u32(seed, g, t, ESIM_SLOT_ROOM0 + j) < thr; }
+    else hit = esim_u32(seed, g, t, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK) < thr;
     if (hit && expose_once(d, ctrl, m, CW_MAKE(t + TE_BIAS, 0u))) n_exp++;   // Exposed(0), citizen.rs:244
 }
 
@@ -145,7 +145,7 @@ __device__ __forceinline__ void bus_draw(const Dev &d, Ctrl *ctrl, uint32_t c, u
     const uint32_t fl = d.cit[c];
     if (building_draws(d, c, fl, t, mask, at_work)) return;              // the buildings got there first
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
-    if (esim_u53(seed, d.id_base + c, t, ESIM_SLOT_BUS) < threshold(d, fl, mask, k)) {
+    if (esim_u32(seed, d.id_base + c, t, ESIM_SLOT_BUS) < threshold(d, fl, mask, k)) {
         if (expose_once(d, ctrl, c, CW_MAKE(t + TE_BIAS, CW_BUS_EXPOSED))) {
             atomicAdd(&d.exp_step[2u * t + 1u], 1u);
             if (ctrl->have_elig) atomicSub(&ctrl->elig_count, 1u);       // simulator.rs:447-449 (a Susceptible is eligible)

@@ -40,21 +40,22 @@ ESIM_HD philox_out philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t
     return o;
 }
 
-// 53-bit integer of the exposure draw for (citizen, step, slot): uniform = u53 * 2^-53.  Steps 2k and 2k+1 share the block
-// (citizen, k, slot): the even step takes words (0,1), the odd one (2,3) -- all 128 bits of a block are used.
-ESIM_HD uint64_t esim_u53_of(const philox_out &o, uint32_t step)
+// 32-bit integer of the exposure draw for (citizen, step, slot): uniform = word * 2^-32.  Steps 4k .. 4k+3 share the block
+// (citizen, k, slot), step t takes its word t & 3 -- all 128 bits of a block are used.
+ESIM_HD uint32_t esim_u32_of(const philox_out &o, uint32_t step)
 {
-    return (step & 1u) ? ((((uint64_t)o.w2 << 32) | o.w3) >> 11) : ((((uint64_t)o.w0 << 32) | o.w1) >> 11);
+    const uint32_t h = step & 3u;
+    return h == 0u ? o.w0 : h == 1u ? o.w1 : h == 2u ? o.w2 : o.w3;
 }
 
 ESIM_HD philox_out esim_draw_block(uint64_t seed, uint32_t citizen, uint32_t step, uint32_t slot)
 {
-    return philox4x32_10(citizen, step >> 1, slot, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return philox4x32_10(citizen, step >> 2, slot, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
-ESIM_HD uint64_t esim_u53(uint64_t seed, uint32_t citizen, uint32_t step, uint32_t slot)
+ESIM_HD uint32_t esim_u32(uint64_t seed, uint32_t citizen, uint32_t step, uint32_t slot)
 {
-    return esim_u53_of(esim_draw_block(seed, citizen, step, slot), step);
+    return esim_u32_of(esim_draw_block(seed, citizen, step, slot), step);
 }
 
 // draw slots (RNG contract)

@@ -272,7 +272,7 @@ const char *esim_last_error(const esim_ctx *ctx);   /* ctx may be NULL: last esi
 void esim_destroy(esim_ctx *ctx);
 
 /* The exposure-probability LUT the kernels use: thresholds[mask][n & 255] =
- * ceil(q * 2^53) with q = 1 - (1 - p_eff)^(n as u8) (citizen.rs:47-49,239;
+ * ceil(q * 2^32) with q = 1 - (1 - p_eff)^(n as u8) (citizen.rs:47-49,239;
  * disease.rs:131-154).  mask 0: p_eff = p, mask 1: p_eff = p - p*mask_effectiveness.
  * Pure host arithmetic; exported so parity tests can pin it. */
 int  esim_threshold_lut(const esim_params *p, uint64_t out[512]);

@@ -51,19 +51,19 @@ static void philox_block(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, u
     orc_philox4x32_10(ctr, key, out);
 }
 
-/* The 53-bit integer of the exposure draw of citizen c0 in step c1, slot c2: steps 2k and 2k+1 share one block, the even
- * step takes its words (0,1), the odd one (2,3) -- all 128 bits of a block are used (RNG contract, esim_oracle.h). */
-uint64_t orc_u53(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2)
+/* The 32-bit integer of the exposure draw of citizen c0 in step c1, slot c2: steps 4k .. 4k+3 share one block, step t takes
+ * its word t & 3 -- all 128 bits of a block are used (RNG contract, esim_oracle.h). */
+uint32_t orc_u32(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2)
 {
     uint32_t w[4];
-    philox_block(seed, c0, c1 >> 1, c2, w);
-    return (c1 & 1u) ? ((((uint64_t)w[2] << 32) | w[3]) >> 11) : ((((uint64_t)w[0] << 32) | w[1]) >> 11);
+    philox_block(seed, c0, c1 >> 2, c2, w);
+    return w[c1 & 3u];
 }
 
 /* Uniform in [0,1) replacing RANDOM_DISTRUBUTION.sample(rng) (citizen.rs:44,242) */
 static double uniform01(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2)
 {
-    return (double)orc_u53(seed, c0, c1, c2) * 0x1.0p-53;
+    return (double)orc_u32(seed, c0, c1, c2) * 0x1.0p-32;
 }
 
 /* ------------------------------------------------------------- probability */

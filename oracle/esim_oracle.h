@@ -25,11 +25,11 @@
  *
  * RNG CONTRACT (shared, by specification, with the HIP implementation):
  *   block(c0,c1,c2,c3) = Philox4x32-10(counter=(c0,c1,c2,c3), key=(seed_lo,seed_hi))
- *   u53(a, b)   = ((a << 32 | b) >> 11)                      -- 53-bit integer
- *   uniform     = u53 * 2^-53  in [0,1)
+ *   uniform     = w * 2^-32  in [0,1) for a 32-bit word w of a block (the reference's Uniform<f64> has 52 random bits,
+ *        citizen.rs:44; the probabilities differ by less than 2^-32)
  *   exposure draw for citizen g (GLOBAL index) in step t, slot s:
- *        (w0,w1,w2,w3) = block(g, t >> 1, s, 0);  u53(w0,w1) for even t, u53(w2,w3) for odd t -- two steps per block, all
- *        128 bits used;  success  <=>  uniform < q   (strict, citizen.rs:242)
+ *        w = word t & 3 of block(g, t >> 2, s, 0) -- four consecutive steps per block, all 128 bits used;
+ *        success  <=>  uniform < q   (strict, citizen.rs:242)
  *        s = 0  draw from the home building's list          (building.rs:202)
  *        s = 1  draw from a non-school work building's list (building.rs:278)
  *        s = 2  draw on a bus                               (simulator.rs:436)
@@ -131,7 +131,7 @@ double   orc_binomial(double probability, uint8_t n);                 /* citizen
 double   orc_exposure_chance(const orc_params *p, int is_vaccinated, int mask_status,
                              int on_pt_and_compliant);                /* disease.rs:131-154 */
 double   orc_q(const orc_params *p, uint64_t n, int mask_compliant, int global_mask); /* citizen.rs:221-240 */
-uint64_t orc_u53(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2);
+uint32_t orc_u32(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2);
 
 #ifdef __cplusplus
 }

@@ -109,7 +109,7 @@ static bool expose(rsh_sim *s, Citizen &z, uint64_t exposure_total, uint32_t slo
     const int mask = z.is_mask_compliant ? ORC_MASK_NONE : s->mask;
     const double chance = orc_exposure_chance(&s->P, z.status == ORC_V, mask, z.is_mask_compliant && z.on_bus);
     const double q = orc_binomial(chance, (uint8_t)exposure_total);
-    if (z.status == ORC_S && (double)orc_u53(s->P.seed, z.global_index, s->time_step, slot) * 0x1.0p-53 < q) {
+    if (z.status == ORC_S && (double)orc_u32(s->P.seed, z.global_index, s->time_step, slot) * 0x1.0p-32 < q) {
         z.status = ORC_E; z.timer = 0;
         return true;
     }

@@ -55,8 +55,8 @@ def lib():
         L.orc_exposure_chance.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int]
         L.orc_q.restype = C.c_double
         L.orc_q.argtypes = [C.POINTER(Params), C.c_uint64, C.c_int, C.c_int]
-        L.orc_u53.restype = C.c_uint64
-        L.orc_u53.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_u32.restype = C.c_uint32
+        L.orc_u32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
         _lib = L
     return _lib

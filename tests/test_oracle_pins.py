@@ -73,7 +73,7 @@ def test_exposure_chance_matches_reference_formula():
 
 
 def test_library_lut_equals_oracle_probabilities():
-    """The integer thresholds libesim uploads are ceil(q*2^53) of the oracle's f64 q."""
+    """The integer thresholds libesim uploads are ceil(q*2^32) of the oracle's f64 q."""
     import math
     lib = _lib.load()
     lut = (C.c_uint64 * 512)()
@@ -84,12 +84,12 @@ def test_library_lut_equals_oracle_probabilities():
     for row, (compliant, mask) in enumerate(((1, 0), (0, 2))):
         for n in range(256):
             q = L.orc_q(C.byref(prm), n, compliant, mask)
-            assert lut[row * 256 + n] == math.ceil(math.ldexp(q, 53))
-    # u < q  <=>  u53 < threshold, checked on the two integers around each threshold
+            assert lut[row * 256 + n] == math.ceil(math.ldexp(q, 32))
+    # u < q  <=>  u32 < threshold, checked on the two integers around each threshold
     for n in (1, 2, 10, 255):
         thr = lut[n]
         q = L.orc_q(C.byref(prm), n, 1, 0)
-        assert (thr - 1) * 2.0 ** -53 < q and not (thr * 2.0 ** -53 < q)
+        assert (thr - 1) * 2.0 ** -32 < q and not (thr * 2.0 ** -32 < q)
 
 
 def tiny_world(n_homes=3, per_home=2, **flags):
@@ -208,8 +208,8 @@ def test_oracle_golden_trajectory_fixture():
 def test_oracle_meets_the_reference_recorded_york_run():
     """THE pin between the oracle and something the reference produced.  The reference's one recorded run with the current
     parameters (York, v1.7.1: 197 603 citizens, 5000 steps, 85 vaccinations per step) is a single OS-seeded sample, so the
-    comparison is distributional: the oracle runs the `york` preset under 8 (population seed, Philox seed) pairs with those
-    parameters, and every fact the fixture holds about the reference's records must lie inside the spread of the 8 runs
+    comparison is distributional: the oracle runs the `york` preset under 16 (population seed, Philox seed) pairs with those
+    parameters, and every fact the fixture holds about the reference's records must lie inside the spread of the 16 runs
     widened by WIDEN.  The facts about the records' timing and peaks were used to calibrate the one input of the synthetic
     population that no log of the reference pins (dwellings OSM tags per Output Area, popgen.cpp); the facts from
     exposures.json (total exposures of the run, Output Areas that saw any, their concentration) were not.
@@ -219,7 +219,7 @@ def test_oracle_meets_the_reference_recorded_york_run():
     with open(os.path.join(GOLDEN, "reference_york_v171_envelope.json")) as f:
         env = json.load(f)
     assert env["n_citizens"] == 197603 and env["recovered_decreases"] is True       # Q10: vaccination relabels Recovered
-    runs = _envelope.ensemble(8, steps=5000, workers=min(4, os.cpu_count() or 1))
+    runs = _envelope.ensemble(16, steps=5000, workers=min(8, os.cpu_count() or 1))
 
     def inside(name, ref, values, widen=WIDEN):
         got = [v for v in values if v is not None]
