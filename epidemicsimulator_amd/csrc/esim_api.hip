@@ -351,6 +351,8 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     c->cnt_base = cnt;
     c->cnt_bytes = sizeof(uint32_t) * MARK_SLOTS * per_parity;
     if ((rc = dev_alloc(c, &d.exp_step, 2 * ((size_t)c->P.max_steps + 2)))) return rc;
+    if ((rc = dev_alloc(c, &d.exp_part, (size_t)EXP_ROWS * 2u * FREE_MAX))) return rc;
+    HIP_TRY(c, hipMemset(d.exp_part, 0, sizeof(uint32_t) * EXP_ROWS * 2u * FREE_MAX));
     if ((rc = dev_alloc(c, &d.dec, FREE_MAX + 1))) return rc;
     // hash map of the time-parallel chunks: room for ~2 marks per (Infected, step) pair at < 1/2 load
     {
@@ -694,7 +696,7 @@ void enqueue_parallel_chunk(esim_ctx_impl *c, int then_next, uint32_t limit_t)
     hipLaunchKernelGGL(k_chunk_fold, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
-    if (!small) hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);
+    if (!small) hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, small ? 1 : 0, then_next, (uint32_t)c->xf_n, limit_t);
     if (!small) hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d);
 }
@@ -713,7 +715,7 @@ void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
     hipLaunchKernelGGL(k_chunk_fold, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
-    hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, 0, 0, (uint32_t)c->xf_n, limit_t);
     hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_vax_final, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d);
@@ -1099,7 +1101,7 @@ int enqueue_sharded_chunk(esim_ctx_impl *c, uint32_t limit_t, bool vax)
     hipLaunchKernelGGL(k_chunk_fold, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
-    hipLaunchKernelGGL(k_chunk_count, dim3(256), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
     if (vax && (rc = exchange_buf(c, 5, d.xc, FREE_MAX + 2u))) return rc;
     hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, 0, 0, (uint32_t)c->xf_n, limit_t);
     hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d);

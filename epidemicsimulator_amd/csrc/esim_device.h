@@ -149,6 +149,7 @@ struct Dev {
     uint32_t *touched_bld[MARK_SLOTS], *touched_room[MARK_SLOTS], *touched_route[MARK_SLOTS], *touched_route_big[MARK_SLOTS];
     uint32_t *route_flag[MARK_SLOTS];    // [n_routes]
     uint32_t *exp_step;         // [2 * (max_steps + 2)] successful exposures per step: [2t] buildings, [2t+1] buses
+    uint32_t *exp_part;         // [EXP_ROWS][2 * FREE_MAX] the same for the steps of a chunk, by workgroup of k_chunk_count % EXP_ROWS
     struct Decision *dec;       // [FREE_MAX + 1]
     // time-parallel chunks: infected per (building | room | route, step of the chunk) in an open-addressing hash map
     unsigned long long *hkey;   // [hcap] slot id (building | n_bld + room | n_bld + n_room + route), HKEY_EMPTY when free
@@ -249,5 +250,7 @@ struct Dev {
 #define HOT_COUNT 257u
 #define UNIT_NOOP 0xFFFFFFFFu
 #define CHUNK_BUS_STEPS 8u         // a one-pass chunk has at most this many steps with riders on a bus
+#define COUNT_GRID 256u            // workgroups of k_chunk_count
+#define EXP_ROWS 32u
 #define UNIT_PAIRS 256u            // (member, marked step) pairs per deferred unit of a long member list
 #define CHUNK_ROUTE_MAX 2048u      // routes up to this many riders are ranked in LDS by the time-parallel pass

@@ -1492,14 +1492,24 @@ __global__ __launch_bounds__(TPB) void k_chunk_count(Dev d)
     const uint32_t n_new = min(ld(&d.hot[(HOT_NEWEXP + r) * HOT_STRIDE]), d.newexp_cap);
     const uint32_t *list = d.newexp + (size_t)r * d.newexp_cap;
     const uint32_t t0 = ctrl->chunk_t0;
-    // (exp_step of the chunk's steps is zero from reset / from nobody having written it: steps are visited once)
+    // exposures per (step of the chunk, building | bus): counted in LDS, then added to one of EXP_ROWS rows of exp_part
+    // (k_chunk_books adds the rows up and zeroes them) -- a hundred thousand atomics on the same dozen cache lines of one
+    // global array are served one by one
+    __shared__ uint32_t e_cnt[2u * FREE_MAX];
+    __shared__ uint32_t s_cut;
+    if (threadIdx.x < 2u * FREE_MAX) e_cnt[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) s_cut = 0xFFFFFFFFu;
+    __syncthreads();
     for (uint32_t i = tid / SUBQ; i < n_new; i += step) {
         const uint32_t w = d.cit[list[i]];
-        const uint32_t s = CW_TE(w) - TE_BIAS;
-        atomicAdd(&d.exp_step[2u * s + ((w & CW_BUS_EXPOSED) ? 1u : 0u)], 1u);
+        const uint32_t j = CW_TE(w) - TE_BIAS - t0;
+        if (j < FREE_MAX) atomicAdd(&e_cnt[2u * j + ((w & CW_BUS_EXPOSED) ? 1u : 0u)], 1u);
         // exposed on a bus although the plan vaccinates it later in the chunk: from this step on the plan is void (k_chunk_vax)
-        if ((w & CW_BUS_EXPOSED) && CW_VAX_REL(w) != CW_VAX_NONE) { atomicMin(&ctrl->chunk_cut, s - t0); if (d.world > 1u) d.xc[s - t0] = 1u; }
+        if ((w & CW_BUS_EXPOSED) && CW_VAX_REL(w) != CW_VAX_NONE) { atomicMin(&s_cut, j); if (d.world > 1u) d.xc[j] = 1u; }
     }
+    __syncthreads();
+    if (threadIdx.x < 2u * FREE_MAX && e_cnt[threadIdx.x]) atomicAdd(&d.exp_part[(size_t)(blockIdx.x % EXP_ROWS) * 2u * FREE_MAX + threadIdx.x], e_cnt[threadIdx.x]);
+    if (threadIdx.x == 0 && s_cut != 0xFFFFFFFFu) atomicMin(&ctrl->chunk_cut, s_cut);
     if (!ctrl->vax_chunk) return;
     // What the chunk's vaccinations do to the census of its later steps, from the words as the draws left them: one thread per
     // planned citizen, only the step that won counts.  A citizen vaccinated at the end of step j is Vaccinated from step j + 1
@@ -1749,7 +1759,12 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
             const uint32_t w = d.cit[list[i]];
             atomicAdd(&e_cnt[2u * (CW_TE(w) - TE_BIAS - t0) + ((w & CW_BUS_EXPOSED) ? 1u : 0u)], 1u);
         }
-    } else if (tid < 2u * n) e_cnt[tid] = d.exp_step[2u * t0 + tid];           // k_chunk_count made them
+    } else if (tid < 2u * n) {
+        uint32_t a = 0u;                                                      // k_chunk_count made them, in EXP_ROWS rows
+#pragma unroll
+        for (uint32_t p = 0; p < EXP_ROWS; ++p) { a += d.exp_part[(size_t)p * 2u * FREE_MAX + tid]; d.exp_part[(size_t)p * 2u * FREE_MAX + tid] = 0u; }
+        e_cnt[tid] = a;
+    }
     __syncthreads();
     const uint32_t pb1 = PROF_NOW();
     const bool vax = ld(&ctrl->vax_chunk) != 0u;                              // (planned chunks always take the wide form: fused == 0)
