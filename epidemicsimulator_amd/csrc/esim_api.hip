@@ -404,10 +404,10 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         HIP_TRY(c, hipMemset(d.pair_cnt, 0, sizeof(uint32_t) * 16384u));
         d.newexp_cap = N / SUBQ + 1u;                 // citizens with the same id & 63: nobody is listed twice in a chunk
         if ((rc = dev_alloc(c, &d.newexp, (size_t)d.newexp_cap * SUBQ))) return rc;
-        if ((rc = dev_alloc(c, &d.cursor, FREE_MAX))) return rc;
+        if ((rc = dev_alloc(c, &d.cursor, (size_t)EXP_ROWS * FREE_MAX))) return rc;
         HIP_TRY(c, hipMemset(d.hkey, 0xFF, sizeof(unsigned long long) * cap));
         HIP_TRY(c, hipMemset(d.vec, 0, sizeof(uint32_t) * (size_t)cap * FREE_MAX));
-        HIP_TRY(c, hipMemset(d.cursor, 0, sizeof(uint32_t) * FREE_MAX));
+        HIP_TRY(c, hipMemset(d.cursor, 0, sizeof(uint32_t) * EXP_ROWS * FREE_MAX));
     }
     for (int p = 0; p < (int)MARK_SLOTS; ++p) {
         uint32_t *base = cnt + p * per_parity;
@@ -698,7 +698,7 @@ void enqueue_parallel_chunk(esim_ctx_impl *c, int then_next, uint32_t limit_t)
     hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     if (!small) hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, small ? 1 : 0, then_next, (uint32_t)c->xf_n, limit_t);
-    if (!small) hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d);
+    if (!small) hipLaunchKernelGGL(k_chunk_scatter, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);   // (same grid as k_chunk_count: their workgroups pair up)
 }
 
 // One time-parallel chunk under a vaccination programme: census ahead, the plan of the chunk's vaccinations and what it does
@@ -717,7 +717,7 @@ void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
     hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, 0, 0, (uint32_t)c->xf_n, limit_t);
-    hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_scatter, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);   // (same grid as k_chunk_count: their workgroups pair up)
     hipLaunchKernelGGL(k_chunk_vax_final, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d);
 }
 
@@ -1104,7 +1104,7 @@ int enqueue_sharded_chunk(esim_ctx_impl *c, uint32_t limit_t, bool vax)
     hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
     if (vax && (rc = exchange_buf(c, 5, d.xc, FREE_MAX + 2u))) return rc;
     hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, 0, 0, (uint32_t)c->xf_n, limit_t);
-    hipLaunchKernelGGL(k_chunk_scatter, dim3(256), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_scatter, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);   // (same grid as k_chunk_count: their workgroups pair up)
     hipLaunchKernelGGL(k_chunk_vax_final, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d);
     HIP_TRY(c, hipGetLastError());
     return ESIM_OK;

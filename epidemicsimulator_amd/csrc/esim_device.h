@@ -180,7 +180,7 @@ struct Dev {
     uint32_t *newexp;           // [SUBQ][newexp_cap] citizens exposed in the chunk, by id & 63
     uint32_t newexp_cap;
     uint32_t *hot;              // [HOT_COUNT * HOT_STRIDE] the counters of the lists above
-    uint32_t *cursor;           // [FREE_MAX] per-step write cursors into the log
+    uint32_t *cursor;           // [EXP_ROWS][FREE_MAX] write cursors into each step's stretch of the log, a row per EXP_ROWS-th workgroup
     uint32_t max_route;         // riders of the largest route
     // vaccination inside time-parallel chunks
     uint32_t *vax_ev;           // [FREE_MAX][VACC_MAX_RATE] citizens chosen in each step of the chunk, in candidate order

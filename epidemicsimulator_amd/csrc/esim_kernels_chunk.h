@@ -1554,7 +1554,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d)
         for (uint32_t i = tid / SUBQ; i < n_new; i += step) {
             const uint32_t m = list[i];
             const uint32_t te = CW_TE(d.cit[m]);
-            if (te - TE_BIAS - t0 < n_eff) d.log[d.log_off[te] + atomicAdd(&d.cursor[te - TE_BIAS - t0], 1u)] = m;
+            if (te - TE_BIAS - t0 < n_eff) d.log[d.log_off[te] + atomicAdd(&d.cursor[(blockIdx.x % EXP_ROWS) * FREE_MAX + te - TE_BIAS - t0], 1u)] = m;
             else {
                 // exposed in a step that was not committed (a cut, or the disease was over before): Susceptible again; on a bus in
                 // the very step of the cut: it will be again, and the next plan must know (CW_PLAN_SKIP)
@@ -1760,9 +1760,18 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
             atomicAdd(&e_cnt[2u * (CW_TE(w) - TE_BIAS - t0) + ((w & CW_BUS_EXPOSED) ? 1u : 0u)], 1u);
         }
     } else if (tid < 2u * n) {
-        uint32_t a = 0u;                                                      // k_chunk_count made them, in EXP_ROWS rows
+        // k_chunk_count made them, in EXP_ROWS rows by workgroup.  k_chunk_scatter's workgroups visit the same citizens as their
+        // namesakes there, so a row's counts are also what its workgroups will write into each step's stretch of the log: the
+        // rows get their own write cursors (one shared cursor per step is a hundred thousand returning atomics on six lines)
+        uint32_t a = 0u, run = 0u;
 #pragma unroll
-        for (uint32_t p = 0; p < EXP_ROWS; ++p) { a += d.exp_part[(size_t)p * 2u * FREE_MAX + tid]; d.exp_part[(size_t)p * 2u * FREE_MAX + tid] = 0u; }
+        for (uint32_t p = 0; p < EXP_ROWS; ++p) {
+            const uint32_t v = d.exp_part[(size_t)p * 2u * FREE_MAX + tid];
+            d.exp_part[(size_t)p * 2u * FREE_MAX + tid] = 0u;
+            a += v;
+            if (!(tid & 1u)) d.cursor[p * FREE_MAX + (tid >> 1)] = run;      // (buildings + buses of the step, rows before this one)
+            run += v + __shfl_xor(v, 1, 64);
+        }
         e_cnt[tid] = a;
     }
     __syncthreads();
@@ -1775,9 +1784,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
         if (tid < SUBQ) d.hot[(HOT_PREV_NEWEXP + tid) * HOT_STRIDE] = n_new;   // (thread r < 64 read sub-list r's length above)
         if (tid == 0) { ctrl->prev_t0 = t0; ctrl->prev_n_items = n_items; ctrl->prev_per_wave = ld(&ctrl->items_per_wave);
                         ctrl->prev_n = n; ctrl->prev_n_eff = n_eff; ctrl->prev_vax = vax ? 1u : 0u; ctrl->prev_planned = ld(&ctrl->vax_planned); ctrl->vax_chunk = 0u; }
-        // ... and start its per-step write cursors from zero: the scatter of the chunk before this one ran after the
-        // decision step that last cleared them
-        if (tid < FREE_MAX) d.cursor[tid] = 0u;
+        // (its per-step write cursors were set above, a row per EXP_ROWS-th workgroup)
     }
     if (tid == 0) ctrl->chunk_done = 1u;
     if (tid < 64u) {
