@@ -982,9 +982,10 @@ struct RouteShared {
     uint32_t s_cnt[CHUNK_ROUTE_MAX + 1];
 };
 // Per wavefront: the item's / the school's Infected per step; 64 staged members; the item's slots of four time steps
-// (item_steps_regs).  A slot's descriptor is eight words, two per step (time step 4k first): word A = step of the chunk
-// (bits 0-6) | marked (7) | at work (8) | masks everywhere (9) | the school's Infected & 255 (10-17), word B = the item's
-// Infected in that step.
+// (item_steps_regs).  A slot's descriptor is eight words: [0] first step of the slot + 3 (bits 0-6; a slot may begin up to three
+// steps before the chunk) | its steps that are marked (8-11) | in which of them those with a work place are at work (12-15) | in
+// which masks are worn everywhere (16-19); [1] the item's Infected & 255 in the four steps, a byte each (the threshold index,
+// `as u8`); [2] the same for the school of a room; [3], [4] the item's Infected in steps 0-1 / 2-3, 16 bits each.
 #define SLOT_STEPS 4u
 struct WaveScratch { uint32_t cnt[FREE_MAX]; uint32_t sch[FREE_MAX]; uint32_t mem_id[64]; uint32_t mem_w[64]; uint4 desc[2u * (FREE_MAX / SLOT_STEPS + 1u)]; };
 
@@ -1018,47 +1019,51 @@ __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const Chu
             const uint32_t m = ws.mem_id[um - mb], w = ws.mem_w[um - mb];
             const uint32_t te = CW_TE(w);
             if (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) continue;
-            const uint4 dsc0 = ws.desc[2u * si], dsc1 = ws.desc[2u * si + 1u];
-            const uint32_t A[SLOT_STEPS] = { dsc0.x, dsc0.z, dsc1.x, dsc1.z }, cnt[SLOT_STEPS] = { dsc0.y, dsc0.w, dsc1.y, dsc1.w };
-            const uint32_t vrel = CW_VAX_REL(w), keep = w & CW_KEEP;
-            const bool same = w & FL_SAME_AREA, hw = w & FL_HAS_WORK, lax = !(w & FL_MASK_COMPLIANT);
-            bool act[SLOT_STEPS]; uint64_t thr[SLOT_STEPS];
-            bool any = false;
-            uint32_t s_blk = 0u;                                              // a time step of the slot: names its block
+            const uint4 dsc = ws.desc[2u * si];
+            const uint32_t cnt23 = ws.desc[2u * si + 1u].x;
+            const int jb = (int)(dsc.x & 127u) - 3;                            // first step of the slot (may lie before the chunk)
+            const uint32_t mk = (dsc.x >> 8) & 15u, atw = (dsc.x >> 12) & 15u, everywhere = (dsc.x >> 16) & 15u;
+            // The steps of the slot in which this member takes a draw, all four at once: marked; Susceptible when this list is
+            // walked in that step -- w > (step << 19 | the bits an exposure keeps), i.e. never exposed, or so far only by
+            // something that comes later (a later step, or a bus of this step: that exposure may be undercut) --; not Vaccinated
+            // by then (k_chunk_vax); standing in the building's area (simulator.rs:324)
+            const uint32_t vrel = CW_VAX_REL(w);
+            const int js = (int)te + (((w & ~CW_KEEP) & ((1u << CW_TE_SHIFT) - 1u)) ? 1 : 0) - (int)(t0 + TE_BIAS);   // Susceptible in steps j < js
+            const int lim = min(js, vrel == CW_VAX_NONE ? (int)FREE_MAX : (int)vrel + 1) - jb;                  // ... of the slot: h < lim
+            const uint32_t early = lim <= 0 ? 0u : lim >= (int)SLOT_STEPS ? 15u : (1u << lim) - 1u;
+            const bool same = w & FL_SAME_AREA;
+            const uint32_t here = kind == 0u ? (((w & FL_HAS_WORK) && !same) ? ~atw : 15u) : (same ? 15u : atw);
+            const uint32_t act = mk & early & here;
+            if (!act) continue;
+            const uint32_t nn = kind == 2u ? dsc.z : dsc.y;                    // exposure_count & 255 per step: infected in the building
+            const uint32_t row = (w & FL_MASK_COMPLIANT) ? 0u : everywhere;   // steps in which this member's chance is the masked one
+            uint64_t thr[SLOT_STEPS];
 #pragma unroll
-            for (uint32_t h = 0; h < SLOT_STEPS; ++h) {
-                const uint32_t j = A[h] & 127u;
-                const bool atw = (A[h] >> 8) & 1u;
-                // marked; Susceptible when this list is walked in that step (never exposed, or so far only by something that
-                // comes later -- a later step, or a bus of this step: that exposure may be undercut); not Vaccinated by then
-                // (k_chunk_vax); standing in the building's area (simulator.rs:324)
-                act[h] = ((A[h] >> 7) & 1u) && w > (((t0 + j + TE_BIAS) << 19) | keep) && j <= vrel &&
-                         (kind == 0u ? !(atw && hw && !same) : (atw || same));
-                const uint32_t nn = kind == 2u ? (A[h] >> 10) & 255u : cnt[h] & 255u;       // exposure_count: infected in the building
-                thr[h] = sm.thr[((lax && ((A[h] >> 9) & 1u)) ? 256u : 0u) + nn];
-                if (act[h]) { any = true; s_blk = t0 + j; }
-            }
-            if (!any) continue;
+            for (uint32_t h = 0; h < SLOT_STEPS; ++h) thr[h] = sm.thr[(((row >> h) & 1u) << 8) + ((nn >> (8u * h)) & 255u)];
             const uint32_t gid = d.id_base + m;
+            const uint32_t s_blk = (uint32_t)((int)t0 + jb) + (uint32_t)__builtin_ctz(act);   // a time step of the slot: names its block
             uint32_t hit = 0u;                                                // bit h: a draw of step h succeeded
             if (kind == 2u) {
                 // School::find_exposures: one draw per Infected in the room (building.rs:494-522); the earliest step decides
-                uint32_t kmax = 0u, first_act = SLOT_STEPS;
+                const uint32_t cnt[SLOT_STEPS] = { dsc.w & 0xFFFFu, dsc.w >> 16, cnt23 & 0xFFFFu, cnt23 >> 16 };
+                uint32_t kmax = 0u;
 #pragma unroll
-                for (uint32_t h = SLOT_STEPS; h-- > 0u;) if (act[h]) { kmax = max(kmax, cnt[h]); first_act = h; }
-                for (uint32_t k = 0; k < kmax && !((hit >> first_act) & 1u); ++k) {
+                for (uint32_t h = 0; h < SLOT_STEPS; ++h) if ((act >> h) & 1u) kmax = max(kmax, cnt[h]);
+                const uint32_t first_act = act & (0u - act);
+                for (uint32_t k = 0; k < kmax && !(hit & first_act); ++k) {
                     const philox_out o = esim_draw_block(seed, gid, s_blk, ESIM_SLOT_ROOM0 + k);
                     const uint32_t wd[SLOT_STEPS] = { o.w0, o.w1, o.w2, o.w3 };
 #pragma unroll
-                    for (uint32_t h = 0; h < SLOT_STEPS; ++h) if (act[h] && k < cnt[h] && (uint64_t)wd[h] < thr[h]) hit |= 1u << h;
+                    for (uint32_t h = 0; h < SLOT_STEPS; ++h) if (((act >> h) & 1u) && k < cnt[h] && (uint64_t)wd[h] < thr[h]) hit |= 1u << h;
                 }
             } else {
                 const philox_out o = esim_draw_block(seed, gid, s_blk, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK);
                 const uint32_t wd[SLOT_STEPS] = { o.w0, o.w1, o.w2, o.w3 };
 #pragma unroll
-                for (uint32_t h = 0; h < SLOT_STEPS; ++h) if (act[h] && (uint64_t)wd[h] < thr[h]) hit |= 1u << h;
+                for (uint32_t h = 0; h < SLOT_STEPS; ++h) if ((uint64_t)wd[h] < thr[h]) hit |= 1u << h;
+                hit &= act;
             }
-            if (hit) expose_min(d, ctrl, m, w, t0 + (((hit & 1u) ? A[0] : (hit & 2u) ? A[1] : (hit & 4u) ? A[2] : A[3]) & 127u), 0u);   // (the earliest wins anyway)
+            if (hit) expose_min(d, ctrl, m, w, (uint32_t)((int)t0 + jb) + (uint32_t)__builtin_ctz(hit), 0u);   // (the earliest wins anyway)
         }
     }
 }
@@ -1084,15 +1089,22 @@ __device__ __forceinline__ uint32_t item_steps_regs(uint32_t c0, uint32_t c1, ui
     for (uint32_t h = 0; h < SLOT_STEPS; ++h) { mk[h] = lane <= FREE_MAX / SLOT_STEPS ? marked(j0 + (int)h) : 0u; any |= mk[h]; }
     const unsigned long long present = __ballot(any != 0u);
     if (any) {
-        auto word_a = [&](int j, uint32_t m) -> uint32_t {
+        uint32_t atw = 0u, everywhere = 0u, nn = 0u, ns = 0u, c01 = 0u, c23 = 0u;
+#pragma unroll
+        for (uint32_t h = 0; h < SLOT_STEPS; ++h) {
+            const int j = j0 + (int)h;
             const uint32_t jc = (uint32_t)(j < 0 ? 0 : j >= (int)FREE_MAX ? (int)FREE_MAX - 1 : j);
             const Decision &q = sm.dec[jc];
-            return ((uint32_t)j & 127u) | (m << 7) | ((q.at_work ? 1u : 0u) << 8) | ((q.mask == ESIM_MASK_EVERYWHERE ? 1u : 0u) << 9) | ((ws.sch[jc] & 255u) << 10);
-        };
-        auto word_b = [&](int j, uint32_t m) -> uint32_t { return m ? ws.cnt[j] : 0u; };
+            const uint32_t c = mk[h] ? ws.cnt[jc] : 0u;
+            atw |= (q.at_work ? 1u : 0u) << h;
+            everywhere |= (q.mask == ESIM_MASK_EVERYWHERE ? 1u : 0u) << h;
+            nn |= (c & 255u) << (8u * h);
+            ns |= (ws.sch[jc] & 255u) << (8u * h);
+            if (h < 2u) c01 |= min(c, 0xFFFFu) << (16u * h); else c23 |= min(c, 0xFFFFu) << (16u * (h - 2u));
+        }
         const uint32_t i = (uint32_t)__popcll(present & ((1ull << lane) - 1ull));
-        ws.desc[2u * i] = make_uint4(word_a(j0, mk[0]), word_b(j0, mk[0]), word_a(j0 + 1, mk[1]), word_b(j0 + 1, mk[1]));
-        ws.desc[2u * i + 1u] = make_uint4(word_a(j0 + 2, mk[2]), word_b(j0 + 2, mk[2]), word_a(j0 + 3, mk[3]), word_b(j0 + 3, mk[3]));
+        ws.desc[2u * i] = make_uint4((uint32_t)(j0 + 3) | ((mk[0] | (mk[1] << 1) | (mk[2] << 2) | (mk[3] << 3)) << 8) | (atw << 12) | (everywhere << 16), nn, ns, c01);
+        ws.desc[2u * i + 1u] = make_uint4(c23, 0u, 0u, 0u);
     }
     return (uint32_t)__popcll(present);
 }
