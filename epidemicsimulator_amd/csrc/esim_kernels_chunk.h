@@ -1651,14 +1651,26 @@ __device__ __forceinline__ uint32_t batch_finish_body(const Dev &d, uint32_t t0,
         else if (k >= 0) h = d.hist[k];
         P[tid + 1] = h;
         if (tid == 0) { P[0] = 0u; n_eff_s = n_cut; }
-        if (tid < 5u) {
-            // cum[q][i] = sum of delta[q][0..i] (i.e. what applies to step i); cum[4][i] = bus exposures of steps < i
-            uint32_t a = 0;
-            for (uint32_t i = 0; i < FREE_MAX + 2u; ++i) {
-                if (tid < 4u) { a += vax ? ld(&d.vax_delta[tid * (FREE_MAX + 2u) + i]) : 0u; cum[tid][i] = a; }
-                else { cum[4][i] = a; if (i < n) a += e ? e[2u * i + 1u] : d.exp_step[2u * (t0 + i) + 1u]; }
-            }
+        // cum[q][i] = sum of delta[q][0..i] (i.e. what applies to step i); cum[4][i] = bus exposures of steps < i.
+        // (all loads at once, then one wavefront per row scans it: a thread walking a row load by load took 15-25 us)
+        for (uint32_t i = tid; i < 5u * (FREE_MAX + 2u); i += FIN_TPB) {
+            const uint32_t q = i / (FREE_MAX + 2u), k = i - q * (FREE_MAX + 2u);
+            uint32_t v = 0u;
+            if (q < 4u) v = vax ? ld(&d.vax_delta[i]) : 0u;
+            else if (k < n) v = e ? e[2u * k + 1u] : d.exp_step[2u * (t0 + k) + 1u];
+            cum[q][k] = v;
         }
+    }
+    __syncthreads();
+    if (tid < 5u * 64u) {
+        const uint32_t q = tid >> 6, l = tid & 63u;
+        uint32_t v0 = cum[q][l], v1 = 64u + l < FREE_MAX + 2u ? cum[q][64u + l] : 0u;
+        const uint32_t own0 = v0, own1 = v1;
+        for (uint32_t o = 1; o < 64u; o <<= 1) { const uint32_t y0 = __shfl_up(v0, o, 64), y1 = __shfl_up(v1, o, 64); if (l >= o) { v0 += y0; v1 += y1; } }
+        v1 += __shfl(v0, 63, 64);
+        if (q == 4u) { v0 -= own0; v1 -= own1; }                              // (exclusive: bus exposures of the steps before)
+        cum[q][l] = v0;
+        if (64u + l < FREE_MAX + 2u) cum[q][64u + l] = v1;
     }
     __syncthreads();
     block_scan_1024(P + 1, wtmp);
