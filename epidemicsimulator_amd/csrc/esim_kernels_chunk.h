@@ -463,8 +463,10 @@ __global__ __launch_bounds__(128) void k_shard_prep(Dev d, uint32_t max_ahead, u
 // steps of the chunk are drawn in ONE pass.
 //   k_chunk_marks  an item per building / room / route that somebody Infected stands in during the chunk, and per item the
 //                  stretches of steps in which each of them stands there (generate_exposures)
-//   k_chunk_draw   the (member, marked step) pairs of every item, densely over the lanes (apply_exposures); long member
-//                  lists are cut into units
+//   k_chunk_fold   the stretches that did not fit an item's own records, summed into its per-step counters; the prefix sums
+//                  that let the draw pass take the items in equal shares
+//   k_chunk_draw   the (member, slot of four marked steps) pairs of every item, densely over the lanes (apply_exposures); long
+//                  member lists are cut into units
 //   k_chunk_units  the units, dealt evenly; routes of more than 64 riders
 //   k_chunk_books  exposure counts, records, log entries, clean-up, the next chunk's decisions
 //                  (k_chunk_count / k_chunk_scatter: its two wide parts as kernels of their own while many are Infected)
@@ -480,20 +482,6 @@ __device__ __forceinline__ uint32_t hash64(unsigned long long k)
 // records, the per-step counters of those that found no record free, a route's registered bus steps -- is indexed by the
 // hash SLOT, which the probe itself returns: nobody ever waits for anybody.
 #define ITEM_UNUSED 0xFFFFFFFFu
-__device__ __forceinline__ bool item_probe(const Dev &d, Ctrl *ctrl, unsigned long long key, uint32_t &slot, bool &pending)
-{
-    uint32_t h = hash64(key) & (d.hcap - 1u);
-    pending = false;
-    for (uint32_t probe = 0; probe < d.hcap; ++probe) {
-        const unsigned long long old = atomicCAS(&d.hkey[h], HKEY_EMPTY, key);
-        if (old == HKEY_EMPTY) { slot = h; return true; }
-        if (old == key) { slot = h; pending = true; return false; }
-        h = (h + 1u) & (d.hcap - 1u);
-    }
-    ctrl->error = (uint32_t)(-ESIM_ERANGE);
-    slot = 0u;
-    return false;
-}
 
 // An interval record: a citizen that is Infected in steps [a, b] of the chunk, the flags that decide where it stands
 // in each of them, and whether the record sits in its work building / room or in its home.
