@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--no-extra-runs", action="store_true", help="skip the full-length and vaccination-regime runs")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (this pool's driver supports dmabuf IPC only: RCCL needs it)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -155,7 +156,22 @@ def main():
         n_total, n_areas = spec.n_citizens * mult, spec.n_areas * mult
         pop = Population.synthetic_shard(rank, world, args.preset, n_citizens=n_total, n_areas=n_areas)
         params = _lib.default_params(max_steps=max(steps, warmup, 1))
-        sim = ShardedSimulator(None, rank, world, params, device_index=local_rank, shard_population=pop, transport=args.transport)
+        def make(transport):
+            return ShardedSimulator(None, rank, world, params, device_index=local_rank, shard_population=pop, transport=transport)
+        sim, transport_used, transport_note = None, args.transport, None
+        try:
+            sim = make(args.transport)
+        except Exception as ex:            # (e.g. librccl not loadable: the same on every rank)
+            transport_note = str(ex)
+        failed = torch.tensor([0 if sim is not None else 1], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(failed)
+        if int(failed.item()) > 0:
+            if args.transport != "rccl":
+                raise SystemExit("the sharded context could not be created: %s" % transport_note)
+            if sim is not None:
+                sim.close()
+            sim, transport_used = make("callback"), "callback"
+            transport_note = "the library's RCCL communicator could not be set up on %d rank(s) (%s); its callback transport into torch.distributed (%s) was used" % (int(failed.item()), transport_note, backend)
 
         def fence():
             sim.synchronize()
@@ -187,10 +203,10 @@ def main():
                 "config": {"workload": "%s%s: %d citizens, %d Output Areas, %d seeds, %d steps, interventions on; Output Areas sharded in bands of the "
                                        "map over %d GPUs; time-parallel chunks with one round of exchanges per chunk, coupled steps (two exchanges per step) where a chunk cannot run; the library's exchange goes over %s"
                                        % (args.preset, " x %d" % mult if mult > 1 else "", n_total, n_areas, spec.n_seeds, steps, world,
-                                          "its own RCCL communicator" if args.transport == "rccl" else "its callback transport (%s)" % backend),
+                                          "its own RCCL communicator" if transport_used == "rccl" else "its callback transport (%s)" % backend),
                            "citizens_per_gpu": [int(g[0]) for g in gathered], "shared_buildings": int(gathered[0][1]), "shared_rooms": int(gathered[0][2]),
                            "collectives": sim.collectives(), "chunk_steps": sim.shard_stats()["chunk_steps"],
-                           "coupled_steps": sim.shard_stats()["coupled_steps"], "seed": int(params.seed)},
+                           "coupled_steps": sim.shard_stats()["coupled_steps"], "seed": int(params.seed), "transport": transport_used, "transport_note": transport_note},
                 "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                              "note": "per-step exchange form: bound by kernel boundaries and collective latency, not by HBM (DESIGN.md 7); the one-GPU line "
                                      "carries the counter-based figure"},
