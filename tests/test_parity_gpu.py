@@ -408,6 +408,18 @@ def test_many_infected_several_chunks_per_call():
         run_both(pop, 500, check_state_every=block, small_limits=("tp",), **params)
 
 
+@pytest.mark.parametrize("grid", (16, 48))
+def test_chunk_pass_with_few_wavefronts(grid, monkeypatch):
+    # 64 / 192 wavefronts instead of 4096 (ESIM_GRID_CHUNK, read at upload): the lane-per-citizen marks pass then needs several
+    # rounds of 64 citizens per wavefront, the draw pass's equal shares of the items span many owners (192 is no power of two:
+    # the share arithmetic and the two-level owner search), k_chunk_fold's lists are long, an item's records overflow.
+    monkeypatch.setenv("ESIM_GRID_CHUNK", str(grid))
+    pop = random_population(4242 + grid, n=9000, n_areas=9, n_buildings=500, n_schools=4, rooms_per_school=6)
+    params = dict(exposure_chance=0.01, seed=99173 + grid, vaccination_rate=400, vaccination_threshold=0.3, lockdown_threshold=0.15,
+                  mask_pt_threshold=0.02, mask_everywhere_threshold=0.2, bus_capacity=20, exposed_time=30, infected_time=100)
+    run_both(pop, 600, check_state_every=97, small_limits=("vax", "tp"), **params)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_populations_all_paths(seed):
     pop = random_population(seed)
