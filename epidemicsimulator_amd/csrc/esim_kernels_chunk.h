@@ -975,7 +975,7 @@ struct RouteShared {
 // which masks are worn everywhere (16-19); [1] the item's Infected & 255 in the four steps, a byte each (the threshold index,
 // `as u8`); [2] the same for the school of a room; [3], [4] the item's Infected in steps 0-1 / 2-3, 16 bits each.
 #define SLOT_STEPS 4u
-struct WaveScratch { uint32_t cnt[FREE_MAX]; uint32_t sch[FREE_MAX]; uint32_t mem_id[64]; uint32_t mem_w[64]; uint4 desc[2u * (FREE_MAX / SLOT_STEPS + 1u)]; };
+struct WaveScratch { uint32_t rounds; uint32_t cnt[FREE_MAX]; uint32_t sch[FREE_MAX]; uint32_t mem_id[64]; uint32_t mem_w[64]; uint4 desc[2u * (FREE_MAX / SLOT_STEPS + 1u)]; };
 
 // One member list of one item over the marked steps of the chunk.  The time steps 4k .. 4k+3 share one Philox block (RNG
 // contract: step t takes word t & 3), so the unit of work is a (member, slot of four steps) pair: the pairs [p_lo, p_hi) are
@@ -1002,6 +1002,9 @@ __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const Chu
         }
         __builtin_amdgcn_wave_barrier();
         const uint32_t q_lo = max(p_lo, mb * S), q_hi = min(p_hi, (mb + 64u) * S);
+#ifdef ESIM_WAVE_PROFILE
+        if (lane == 0) ws.rounds += (q_hi - q_lo + 63u) / 64u;
+#endif
         for (uint32_t p = q_lo + lane; p < q_hi; p += 64u) {
             const uint32_t um = p / S, si = p - um * S;
             const uint32_t m = ws.mem_id[um - mb], w = ws.mem_w[um - mb];
@@ -1264,6 +1267,9 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     schedule_masks(lane, n, q0, q1, AW, BUS);
     if (d_lo < d_hi) sl_cur = fetch_slot(d, FX(id_cur, LANE_HSLOT), lane);
     if (have) { const uint32_t r = code_l >> 7; off_l = d.route_off[r]; sz_l = d.route_off[r + 1] - off_l; }
+#ifdef ESIM_WAVE_PROFILE
+    if (lane == 0) ws.rounds = 0u;
+#endif
     const uint32_t pt1 = PROF_NOW();
     // (1) buildings and school rooms: one wavefront per item
     for (uint32_t v = d_lo; v < d_hi; ++v) {
@@ -1365,7 +1371,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     const uint32_t pt3 = PROF_NOW();
 #ifndef ESIM_PROFILE_UNITS
     PROF_PUT(d, 0, pt0); PROF_PUT(d, 1, pt1); PROF_PUT(d, 2, pt2); PROF_PUT(d, 3, pt3);   // start, after preamble, after items, end
-    PROF_PUT(d, 4, p_items); PROF_PUT(d, 5, p_item_max);
+    PROF_PUT(d, 4, p_items); PROF_PUT(d, 5, p_item_max); PROF_PUT(d, 6, wsc[threadIdx.x >> 6].rounds);
 #endif
     (void)pt0; (void)pt1; (void)pt2; (void)pt3; (void)p_items; (void)p_item_max;
 }

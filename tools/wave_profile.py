@@ -25,6 +25,8 @@ for target in targets:
           "(waves with items %d, most items %d, longest item %.1f) | routes phase med %.1f max %.1f"
           % (target, khz.value, us(r[:, 0].max() - t0), us(r[:, 3].max() - t0), np.median(pre), pre.max(), np.median(items), items.max(),
              busy.sum(), r[:, 4].max(), us(r[:, 5].max()), np.median(routes), routes.max()))
+    print("        draw: items in all %d, 64-pair rounds drawn on the spot %d (%.2f per item); items phase per item %.2f us, per round %.2f us"
+          % (r[:, 4].sum(), r[:, 6].sum(), r[:, 6].sum() / max(1, r[:, 4].sum()), items.sum() / max(1, r[:, 4].sum()), items.sum() / max(1, r[:, 6].sum())))
     m0 = r[:, 8].min()
     mt = us(r[:, 9] - r[:, 8])
     print("        marks: starts within %.1f us, span %.1f us | wave med %.1f max %.1f | waves with entries %d, most entries %d"
