@@ -707,8 +707,7 @@ void enqueue_parallel_chunk(esim_ctx_impl *c, int then_next, uint32_t limit_t)
 void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
 {
     Dev &d = c->d;
-    hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
-    hipLaunchKernelGGL(k_chunk_vax, dim3(FREE_MAX), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 0);
+    hipLaunchKernelGGL(k_chunk_vax, dim3(FREE_MAX + 1u), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 0);   // (+ the census ahead)
     hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 0);
     hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);

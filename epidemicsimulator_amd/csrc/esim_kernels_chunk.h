@@ -274,10 +274,18 @@ __global__ __launch_bounds__(TPB) void k_vax_live(Dev d, uint32_t max_ahead, uin
 
 // sharded: the liveness of the candidates comes from buffer V (k_vax_live, all-reduced), every shard walks the same sequence
 // and accepts the same candidates, and keeps the events of its own citizens.
+// Launched with one workgroup more than there are steps, that one makes the census ahead (k_future's work: nothing the plan reads
+// or writes, and a kernel boundary costs as much as the census).
 __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead, uint32_t limit_t, int sharded)
 {
     __shared__ FinishShared sm;
     __shared__ uint32_t n_local;
+    if (blockIdx.x >= FREE_MAX) {
+        __shared__ uint32_t win[BF_WIN];
+        __shared__ uint32_t wtmp[FIN_TPB / 64];
+        future_body(d, max_ahead, limit_t, win, wtmp);
+        return;
+    }
     Ctrl *ctrl = d.ctrl;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t j = blockIdx.x;
