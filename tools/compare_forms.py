@@ -1,5 +1,5 @@
 """Diagnostics: the vaccination-planned chunk form (pipeline level 3) against level 2 (sequential steps under a programme) on a
-preset, block by block, down to the first record field and the first citizens that differ.  python tools/dbg_vax2.py preset [block]"""
+preset, block by block, down to the first record field and the first citizens that differ.  python tools/compare_forms.py preset [block]"""
 import sys, ctypes as C, numpy as np
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 from epidemicsimulator_amd import Population, Simulator, _lib
