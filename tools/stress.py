@@ -1,3 +1,5 @@
+"""A prevalence far beyond the one-pass chunk form's capacity (2 M citizens, up to 39 % Infected at once): the run falls back to
+sequential steps and must still equal the oracle, records and state (diagnostics; the oracle takes ~30 s)."""
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
