@@ -1790,13 +1790,15 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
         // namesakes there, so a row's counts are also what its workgroups will write into each step's stretch of the log: the
         // rows get their own write cursors (one shared cursor per step is a hundred thousand returning atomics on six lines)
         uint32_t a = 0u, run = 0u;
+        uint32_t v[EXP_ROWS];
+#pragma unroll
+        for (uint32_t p = 0; p < EXP_ROWS; ++p) v[p] = d.exp_part[(size_t)p * 2u * FREE_MAX + tid];   // (all loads first: in flight together)
 #pragma unroll
         for (uint32_t p = 0; p < EXP_ROWS; ++p) {
-            const uint32_t v = d.exp_part[(size_t)p * 2u * FREE_MAX + tid];
             d.exp_part[(size_t)p * 2u * FREE_MAX + tid] = 0u;
-            a += v;
+            a += v[p];
             if (!(tid & 1u)) d.cursor[p * FREE_MAX + (tid >> 1)] = run;      // (buildings + buses of the step, rows before this one)
-            run += v + __shfl_xor(v, 1, 64);
+            run += v[p] + __shfl_xor(v[p], 1, 64);
         }
         e_cnt[tid] = a;
     }
