@@ -1070,40 +1070,45 @@ __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const Chu
 // The marked steps of item v as slots of four time steps (4k .. 4k+3), in order, with what member_pairs needs of each step,
 // into this wavefront's scratch (ws.sch holds the school's counts when the item is a room).  Returns S, the number of slots
 // with a marked step.
-__device__ __forceinline__ uint32_t item_steps_regs(uint32_t c0, uint32_t c1, uint32_t lane, WaveScratch &ws, uint32_t t0, const ChunkShared &sm)
+// (four bits of a set of steps from step p on; p may be up to three steps before the chunk)
+__device__ __forceinline__ uint32_t m96_nibble(const M96 &m, int p)
+{
+    if (p < 0) return (uint32_t)(m.lo << (-p)) & 15u;
+    if (p >= 64) return p >= 96 ? 0u : (m.hi >> (p - 64)) & 15u;
+    return (uint32_t)((m.lo >> p) | (p > 60 ? (unsigned long long)m.hi << (64 - p) : 0ull)) & 15u;
+}
+
+// AW / EV: the steps of the chunk in which those with a work place are at work / masks are worn everywhere.
+__device__ __forceinline__ uint32_t item_steps_regs(uint32_t c0, uint32_t c1, uint32_t lane, WaveScratch &ws, uint32_t t0, const M96 &AW, const M96 &EV)
 {
     ws.cnt[lane] = c0;
     if (lane < FREE_MAX - 64u) ws.cnt[64u + lane] = c1;
-    const unsigned long long b0 = __ballot(c0 != 0u), b1 = __ballot(c1 != 0u);
+    const M96 MK = { __ballot(c0 != 0u), (uint32_t)__ballot(lane < FREE_MAX - 64u && c1 != 0u) };
     __builtin_amdgcn_wave_barrier();
     // lane L looks at the slot whose first time step is step j0 = 4L - (t0 & 3) of the chunk (negative: before the chunk)
     const int j0 = (int)(SLOT_STEPS * lane) - (int)(t0 & (SLOT_STEPS - 1u));
-    auto marked = [&](int j) -> uint32_t {
-        if (j < 0 || j >= (int)FREE_MAX) return 0u;
-        return (uint32_t)(((j < 64 ? b0 >> j : b1 >> (j - 64))) & 1ull);
-    };
-    uint32_t mk[SLOT_STEPS];
-    uint32_t any = 0u;
-#pragma unroll
-    for (uint32_t h = 0; h < SLOT_STEPS; ++h) { mk[h] = lane <= FREE_MAX / SLOT_STEPS ? marked(j0 + (int)h) : 0u; any |= mk[h]; }
-    const unsigned long long present = __ballot(any != 0u);
-    if (any) {
-        uint32_t atw = 0u, everywhere = 0u, nn = 0u, ns = 0u, c01 = 0u, c23 = 0u;
+    const uint32_t mk = lane <= FREE_MAX / SLOT_STEPS ? m96_nibble(MK, j0) : 0u;
+    const unsigned long long present = __ballot(mk != 0u);
+    if (mk) {
+        // the counts of the slot's four steps (the item's, the school's), all eight reads in flight together
+        uint32_t c[SLOT_STEPS], sc[SLOT_STEPS];
 #pragma unroll
         for (uint32_t h = 0; h < SLOT_STEPS; ++h) {
             const int j = j0 + (int)h;
             const uint32_t jc = (uint32_t)(j < 0 ? 0 : j >= (int)FREE_MAX ? (int)FREE_MAX - 1 : j);
-            const Decision &q = sm.dec[jc];
-            const uint32_t c = mk[h] ? ws.cnt[jc] : 0u;
-            atw |= (q.at_work ? 1u : 0u) << h;
-            everywhere |= (q.mask == ESIM_MASK_EVERYWHERE ? 1u : 0u) << h;
-            nn |= (c & 255u) << (8u * h);
-            ns |= (ws.sch[jc] & 255u) << (8u * h);
-            if (h < 2u) c01 |= min(c, 0xFFFFu) << (16u * h); else c23 |= min(c, 0xFFFFu) << (16u * (h - 2u));
+            c[h] = ws.cnt[jc]; sc[h] = ws.sch[jc];
+        }
+        uint32_t nn = 0u, ns = 0u;
+#pragma unroll
+        for (uint32_t h = 0; h < SLOT_STEPS; ++h) {
+            if (!((mk >> h) & 1u)) c[h] = 0u;
+            nn |= (c[h] & 255u) << (8u * h);
+            ns |= (sc[h] & 255u) << (8u * h);
         }
         const uint32_t i = (uint32_t)__popcll(present & ((1ull << lane) - 1ull));
-        ws.desc[2u * i] = make_uint4((uint32_t)(j0 + 3) | ((mk[0] | (mk[1] << 1) | (mk[2] << 2) | (mk[3] << 3)) << 8) | (atw << 12) | (everywhere << 16), nn, ns, c01);
-        ws.desc[2u * i + 1u] = make_uint4(c23, 0u, 0u, 0u);
+        ws.desc[2u * i] = make_uint4((uint32_t)(j0 + 3) | (mk << 8) | (m96_nibble(AW, j0) << 12) | (m96_nibble(EV, j0) << 16), nn, ns,
+                                     min(c[0], 0xFFFFu) | (min(c[1], 0xFFFFu) << 16));
+        ws.desc[2u * i + 1u] = make_uint4(min(c[2], 0xFFFFu) | (min(c[3], 0xFFFFu) << 16), 0u, 0u, 0u);
     }
     return (uint32_t)__popcll(present);
 }
@@ -1273,11 +1278,13 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     const Decision q1 = 64u + lane < n ? sm.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
     M96 AW, BUS;
     schedule_masks(lane, n, q0, q1, AW, BUS);
+    const M96 EV = { __ballot(lane < n && q0.mask == ESIM_MASK_EVERYWHERE), (uint32_t)__ballot(64u + lane < n && q1.mask == ESIM_MASK_EVERYWHERE) };
     if (d_lo < d_hi) sl_cur = fetch_slot(d, FX(id_cur, LANE_HSLOT), lane);
     if (have) { const uint32_t r = code_l >> 7; off_l = d.route_off[r]; sz_l = d.route_off[r + 1] - off_l; }
 #ifdef ESIM_WAVE_PROFILE
     if (lane == 0) ws.rounds = 0u;
 #endif
+    uint32_t pst[5] = { 0u, 0u, 0u, 0u, 0u };
     const uint32_t pt1 = PROF_NOW();
     // (1) buildings and school rooms: one wavefront per item
     for (uint32_t v = d_lo; v < d_hi; ++v) {
@@ -1285,10 +1292,12 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
         id_cur = id_nxt;
         if (v + 2u < d_hi) id_nxt = fetch_item(d, id_of(v + 2u), lane);
         if (v + 1u < d_hi) sl_cur = fetch_slot(d, FX(id_cur, LANE_HSLOT), lane);
+        const uint32_t pq0 = PROF_NOW();
         const ItemFetch it = decode_item(d, x, lane, n, AW, BUS);
         if (it.slot == ITEM_UNUSED) continue;
         if (it.id >= route_base) continue;
         const uint32_t pi0 = PROF_NOW();
+        pst[0] += pi0 - pq0;
         (void)pi0; ++p_items;
         if (it.id < d.n_bld) {
             if (it.aux == ESIM_SCHOOL) continue;                              // School::find_exposures works per room
@@ -1299,19 +1308,24 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
             if (lane < n_wrk) wm = d.wrk_idx[it.b_lo + lane];
             if (lane < n_res) rw = d.cit[rm];
             if (lane < n_wrk) ww = d.cit[wm];
-            const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws, t0, sm);
+            const uint32_t pq1 = PROF_NOW();
+            const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws, t0, AW, EV);
             __builtin_amdgcn_wave_barrier();
+            const uint32_t pq2 = PROF_NOW();
             // Household / Workplace::find_exposures: every registered occupant (building.rs:202-204,278-280)
             const UnitSrc src = { it.slot, it.link, FX(x, 7) };
             list_or_units(d, ctrl, sm, ws, d.res_idx, it.a_lo, it.a_hi, src, lane, 0u, S, t0, true, rm, rw);
+            const uint32_t pq3 = PROF_NOW();
             list_or_units(d, ctrl, sm, ws, d.wrk_idx, it.b_lo, it.b_hi, src, lane, 1u, S, t0, true, wm, ww);
+            const uint32_t pq4 = PROF_NOW();
+            pst[1] += pq1 - pi0; pst[2] += pq2 - pq1; pst[3] += pq3 - pq2; pst[4] += pq4 - pq3;
         } else {
             const uint32_t n_mem = it.a_hi - it.a_lo;
             uint32_t mm = 0u, mw = 0u;
             if (lane < n_mem) mm = d.room_idx[it.a_lo + lane];
             school_counts(d, it.link, lane, n, q0, q1, ws);
             if (lane < n_mem) mw = d.cit[mm];
-            const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws, t0, sm);
+            const uint32_t S = item_steps_regs(it.c0, it.c1, lane, ws, t0, AW, EV);
             __builtin_amdgcn_wave_barrier();
             // School::find_exposures: the room once per infected in it (building.rs:494-522)
             const UnitSrc src = { it.slot, it.link, FX(x, 7) };
@@ -1380,7 +1394,9 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
 #ifndef ESIM_PROFILE_UNITS
     PROF_PUT(d, 0, pt0); PROF_PUT(d, 1, pt1); PROF_PUT(d, 2, pt2); PROF_PUT(d, 3, pt3);   // start, after preamble, after items, end
     PROF_PUT(d, 4, p_items); PROF_PUT(d, 5, p_item_max); PROF_PUT(d, 6, wsc[threadIdx.x >> 6].rounds);
+    PROF_PUT(d, 11, pst[0]); PROF_PUT(d, 12, pst[1]); PROF_PUT(d, 13, pst[2]); PROF_PUT(d, 14, pst[3]); PROF_PUT(d, 15, pst[4]);
 #endif
+    (void)pst;
     (void)pt0; (void)pt1; (void)pt2; (void)pt3; (void)p_items; (void)p_item_max;
 }
 
@@ -1412,6 +1428,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
     const Decision q1 = 64u + lane < n ? sm.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
     M96 AW, BUS;
     schedule_masks(lane, n, q0, q1, AW, BUS);
+    const M96 EV = { __ballot(lane < n && q0.mask == ESIM_MASK_EVERYWHERE), (uint32_t)__ballot(64u + lane < n && q1.mask == ESIM_MASK_EVERYWHERE) };
     // Per unit: its record (lanes 0..7 of one register); then, together, the slot's interval records, the school's, and the
     // ids of the first members its pairs touch; then those members' words.  The record of the unit after next and the
     // second stage of the next are in flight while this one draws.
@@ -1450,7 +1467,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
             if (lane < FREE_MAX - 64u) ws.sch[64u + lane] = s1;
         }
         const uint32_t *idx = kind == 2u ? d.room_idx : kind == 1u ? d.wrk_idx : d.res_idx;
-        const uint32_t S = item_steps_regs(c0, c1, lane, ws, t0, sm);
+        const uint32_t S = item_steps_regs(c0, c1, lane, ws, t0, AW, EV);
         __builtin_amdgcn_wave_barrier();
         const uint32_t pairs = n_mem * S;
         member_pairs(d, ctrl, sm, ws, idx, lo, p_lo, min(pairs, p_lo + UNIT_PAIRS), lane, kind, S, t0, true, mid, mw, mf);
