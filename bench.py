@@ -31,6 +31,8 @@ sys.path.insert(0, ROOT)
 MODEL_BYTES_PER_CITIZEN_STEP = 26.0     # state R+W 4, flags 2, home/work/room ids 12, two count gathers 8
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 CENSUS = ("susceptible", "exposed", "infected", "recovered", "vaccinated")
+# the arithmetic the path computes in -- not a precision claim (RNG contract)
+DTYPE = "u32 citizen word; u32 uniform vs ceil(q*2^32) (reference: f64 uniform; tolerance 2^-32 per draw)"
 
 
 def golden_check(preset, rec, seed):
@@ -122,6 +124,7 @@ def main():
     ap.add_argument("--transport", default="rccl", choices=("rccl", "callback"), help="N > 1: the library's own RCCL communicator, or its callback transport into torch.distributed (rehearsal on one GPU)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend of the rendezvous (default gloo: it only carries the unique id, barriers and the timing maximum)")
     ap.add_argument("--no-extra-runs", action="store_true", help="skip the full-length and vaccination-regime runs")
+    ap.add_argument("--comm-timeout", type=float, default=120.0, help="N > 1: deadline (s) of the library's waits inside a sharded run; on expiry the communicator is aborted and the line carries value null")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (this pool's driver supports dmabuf IPC only: RCCL needs it)
@@ -156,36 +159,52 @@ def main():
         n_total, n_areas = spec.n_citizens * mult, spec.n_areas * mult
         pop = Population.synthetic_shard(rank, world, args.preset, n_citizens=n_total, n_areas=n_areas)
         params = _lib.default_params(max_steps=max(steps, warmup, 1))
-        def make(transport):
-            return ShardedSimulator(None, rank, world, params, device_index=local_rank, shard_population=pop, transport=transport)
-        sim, transport_used, transport_note = None, args.transport, None
+        def null_line(reason):
+            """The contract's line without a number: a run that could not be set up or did not finish is not measured."""
+            return {"metric": "citizen-timesteps/sec", "value": None, "unit": "citizen-timesteps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+                    "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+                    "config": {"workload": "%s sharded over %d GPUs" % (args.preset, world), "transport": args.transport}, "error": reason}
+
+        sim, note = None, None
         try:
-            sim = make(args.transport)
-        except Exception as ex:            # (e.g. librccl not loadable: the same on every rank)
-            transport_note = str(ex)
+            sim = ShardedSimulator(None, rank, world, params, device_index=local_rank, shard_population=pop, transport=args.transport,
+                                   timeout_s=args.comm_timeout)
+        except Exception as ex:            # (librccl not loadable, communicator set-up failed, shards that do not belong together)
+            note = "%s: %s" % (type(ex).__name__, ex)
         failed = torch.tensor([0 if sim is not None else 1], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(failed)
         if int(failed.item()) > 0:
-            if args.transport != "rccl":
-                raise SystemExit("the sharded context could not be created: %s" % transport_note)
+            # No silent change of transport: a number measured over the host-staged callback transport is not the RCCL number.
+            # (`--transport callback` asks for that transport explicitly: rehearsals with several ranks on one GPU.)
+            if rank == 0:
+                print(json.dumps(null_line("the sharded context could not be set up over transport '%s' on %d of %d ranks (%s)"
+                                           % (args.transport, int(failed.item()), world, note or "another rank failed"))))
             if sim is not None:
                 sim.close()
-            sim, transport_used = make("callback"), "callback"
-            transport_note = "the library's RCCL communicator could not be set up on %d rank(s) (%s); its callback transport into torch.distributed (%s) was used" % (int(failed.item()), transport_note, backend)
+            dist.destroy_process_group()
+            sys.exit(2)
+        transport_used, transport_note = args.transport, None
 
         def fence():
             sim.synchronize()
             torch.cuda.synchronize()
             dist.barrier()
 
-        sim.run(warmup)
-        fence()
-        sim.reset()
-        fence()
-        t0 = time.perf_counter()
-        sim.run(steps)
-        fence()
-        elapsed = time.perf_counter() - t0
+        try:
+            sim.run(warmup)
+            fence()
+            sim.reset()
+            fence()
+            t0 = time.perf_counter()
+            sim.run(steps)
+            fence()
+            elapsed = time.perf_counter() - t0
+        except Exception as ex:
+            # A device-side error reaches every rank in the same collective (all raise together, same code); a peer that died shows
+            # as ESIM_ETIMEDOUT after the deadline.  Either way this run measured nothing: say so and leave with an error, without
+            # entering another collective that a missing peer would never complete.
+            print(json.dumps(dict(null_line("rank %d: %s: %s" % (rank, type(ex).__name__, ex)), rank=rank)), flush=True)
+            os._exit(3)
         dev = "cuda" if backend == "nccl" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -198,7 +217,7 @@ def main():
             out = {
                 "metric": "citizen-timesteps/sec", "value": n_total * steps / elapsed, "unit": "citizen-timesteps/s",
                 "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
-                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32 citizen word, u64 Philox thresholds",
+                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": DTYPE,
                 "data": "synthetic",
                 "config": {"workload": "%s%s: %d citizens, %d Output Areas, %d seeds, %d steps, interventions on; Output Areas sharded in bands of the "
                                        "map over %d GPUs; time-parallel chunks with one round of exchanges per chunk, coupled steps (two exchanges per step) where a chunk cannot run; the library's exchange goes over %s"
@@ -231,7 +250,7 @@ def main():
     out = {
         "metric": "citizen-timesteps/sec", "value": pop.n_citizens * steps / elapsed, "unit": "citizen-timesteps/s",
         "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 citizen word, u64 Philox thresholds", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": "%s: %d citizens, %d Output Areas, %d seeds, steps 1..%d of 5000, interventions on" % (args.preset, pop.n_citizens, pop.n_areas, spec.n_seeds, steps),
                    "seed": int(params.seed), "timed_region": info},
         "final_record": info["final_record"],

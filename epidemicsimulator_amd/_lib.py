@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ESIM_LIB") or os.path.join(_HERE, "libesim.so")   # ESIM_LIB: a diagnostics build of the same library
 
 OK = 0
-ERRORS = {-1: "EINVAL", -2: "ENODEVICE", -3: "ENOMEM", -4: "ESTATE", -5: "ERANGE", -6: "ESIM"}
+ERRORS = {-1: "EINVAL", -2: "ENODEVICE", -3: "ENOMEM", -4: "ESTATE", -5: "ERANGE", -6: "ESIM", -7: "ETIMEDOUT"}
 
 SUSCEPTIBLE, EXPOSED, INFECTED, RECOVERED, VACCINATED = range(5)
 HOUSEHOLD, WORKPLACE, SCHOOL = range(3)
@@ -89,7 +89,7 @@ SYMBOLS = [
     "esim_default_params", "esim_create", "esim_upload_population", "esim_reset", "esim_step",
     "esim_run", "esim_step_begin", "esim_step_exposures", "esim_step_finish",
     "esim_exchange_buffer", "esim_future_infected", "esim_run_free", "esim_free_begin", "esim_free_enqueue", "esim_free_collect", "esim_set_pipeline", "esim_chunk_timing", "esim_vax_chunk_stats", "esim_pipeline_timing",
-    "esim_comm_unique_id", "esim_comm_init_rccl", "esim_comm_init_callback", "esim_comm_stats", "esim_run_sharded", "esim_shard_stats",
+    "esim_comm_unique_id", "esim_comm_init_rccl", "esim_comm_init_callback", "esim_comm_set_timeout", "esim_debug_inject_error", "esim_comm_stats", "esim_run_sharded", "esim_shard_stats",
     "esim_read_records", "esim_stream", "esim_set_stream",
     "esim_set_exchange_buffer", "esim_synchronize",
     "esim_download_state", "esim_download_exposure_log", "esim_checkpoint_size", "esim_checkpoint_save", "esim_checkpoint_restore", "esim_enable_phase_timing", "esim_phase_timings",
@@ -130,6 +130,8 @@ def load():
         "esim_comm_unique_id": (C.c_int, [vp, C.c_size_t]),
         "esim_comm_init_rccl": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_int]),
         "esim_comm_init_callback": (C.c_int, [vp, ALLREDUCE_FN, vp, C.c_int, C.c_int]),
+        "esim_comm_set_timeout": (C.c_int, [vp, C.c_double]),
+        "esim_debug_inject_error": (C.c_int, [vp, C.c_int]),
         "esim_comm_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "esim_run_sharded": (C.c_int, [vp, C.c_uint32, C.POINTER(C.c_uint32)]),
         "esim_shard_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -7,11 +7,13 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -62,6 +64,7 @@ struct esim_ctx_impl {
     uint32_t *xr = nullptr; size_t xr_n = 0;      // records exchange (sharded chunks)
     uint64_t shard_chunk_steps = 0, shard_step_steps = 0;
     uint64_t comm_calls = 0;
+    double comm_timeout_s = 60.0;      // deadline of a host wait on a stream that holds collectives (esim_comm_set_timeout)
     std::vector<hipEvent_t> fev; size_t fev_used = 0;                               // chunks of an open decoupled burst
     std::vector<hipEvent_t> pkev; size_t pkev_used = 0; uint64_t pipe_steps = 0;   // sampled k_pipe launches
     uint32_t small_max = 128;          // infected-slice length up to which the persistent single-workgroup kernel runs a step
@@ -111,6 +114,15 @@ void free_device(esim_ctx_impl *c)
     for (void *p : c->allocs) (void)hipFree(p);
     c->allocs.clear();
     c->uploaded = false;
+}
+
+// one allocation back (buffers that are re-sized: the commuter segments, the records exchange)
+void dev_free(esim_ctx_impl *c, void *p)
+{
+    if (!p) return;
+    auto it = std::find(c->allocs.begin(), c->allocs.end(), p);
+    if (it != c->allocs.end()) c->allocs.erase(it);
+    (void)hipFree(p);
 }
 
 uint32_t grid_for(size_t items, uint32_t per_block, uint32_t cap)
@@ -183,6 +195,7 @@ extern "C" int esim_create(const esim_params *p, esim_ctx **out)
     if (e != hipSuccess) return fail(nullptr, ESIM_ENODEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
     esim_ctx_impl *c = new esim_ctx_impl();
     c->P = *p;
+    if (const char *e = std::getenv("ESIM_COMM_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0.0) c->comm_timeout_s = v; }
     std::memset(&c->d, 0, sizeof c->d);
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(nullptr, ESIM_ENODEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
@@ -325,6 +338,11 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if (CW_TE(c->init_state[sc]) != seed_te) { c->init_state[sc] = CW_MAKE(seed_te, (uint32_t)fl[sc]); c->init_log.push_back(sc); }
     }
 
+    // a communicator belongs to the population it was set up for (its buffers are sized and its ranks checked against the
+    // shard): a new upload invalidates it -- call esim_comm_init_* again afterwards
+    comm_release(c);
+    c->comm_fn = nullptr; c->comm_user = nullptr; c->comm_rank = 0; c->comm_world = 1;
+    c->xr = nullptr; c->xr_n = 0;
     free_device(c);
     Dev &d = c->d;
     std::memset(&d, 0, sizeof d);
@@ -363,13 +381,18 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if (const char *e = std::getenv("ESIM_HASH_LOG2")) cap = 1u << std::min(28, std::max(4, std::atoi(e)));
         d.hcap = cap;
         d.items_cap = cap / 4u;                     // load factor <= 1/4; one count vector of FREE_MAX steps per item
+        // (every chunk table is initialised at allocation: no kernel ever reads memory nobody wrote, whatever a diagnostics
+        // build leaves out -- and the consumers check what they read from these tables against the capacities)
         if ((rc = dev_alloc(c, &d.hkey, cap))) return rc;
         if ((rc = dev_alloc(c, &d.hitems, d.items_cap))) return rc;
         if ((rc = dev_alloc(c, &d.item_rec, d.items_cap))) return rc;
+        HIP_TRY(c, hipMemset(d.hitems, 0xFF, sizeof(uint32_t) * (size_t)d.items_cap));        // ITEM_UNUSED
+        HIP_TRY(c, hipMemset(d.item_rec, 0, sizeof(ItemRec) * (size_t)d.items_cap));
         if ((rc = dev_alloc(c, &d.vec, (size_t)cap * FREE_MAX))) return rc;
         if ((rc = dev_alloc(c, &d.slot_state, cap))) return rc;
         if ((rc = dev_alloc(c, &d.slot_iv, (size_t)cap * SLOT_IV_STRIDE))) return rc;
         HIP_TRY(c, hipMemset(d.slot_state, 0, sizeof(uint32_t) * cap));
+        HIP_TRY(c, hipMemset(d.slot_iv, 0, sizeof(uint32_t) * (size_t)cap * SLOT_IV_STRIDE));
         // deferred units: SUBQ queues; a queue that is full makes its producer draw the list itself, so the size is a
         // matter of speed only.  Room for the smaller of: every long member list marked in every step; a quarter of the
         // citizens -- twice over, since the queues fill unevenly.
@@ -386,16 +409,24 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if ((rc = dev_alloc(c, &d.units, (size_t)d.unit_qcap * SUBQ))) return rc;
         if ((rc = dev_alloc(c, &d.route_pairs, (size_t)d.items_cap * 2u))) return rc;
         if ((rc = dev_alloc(c, &d.route_pairs_big, (size_t)d.items_cap * 2u))) return rc;
+        HIP_TRY(c, hipMemset(d.units, 0xFF, sizeof(UnitRec) * (size_t)d.unit_qcap * SUBQ));     // code == UNIT_NOOP
+        HIP_TRY(c, hipMemset(d.route_pairs, 0, sizeof(uint32_t) * (size_t)d.items_cap * 2u));
+        HIP_TRY(c, hipMemset(d.route_pairs_big, 0, sizeof(uint32_t) * (size_t)d.items_cap * 2u));
         {
             std::vector<uint32_t> ovf_off(res_off.size());
             for (size_t i = 0; i < res_off.size(); ++i) ovf_off[i] = res_off[i] + wrk_off[i];
             if ((rc = dev_upload(c, &d.ovf_off, ovf_off.data(), ovf_off.size()))) return rc;
             d.ovf_room_base = ovf_off.back();
-            if ((rc = dev_alloc(c, &d.ovf, (size_t)d.ovf_room_base + room_off.back() + 1u))) return rc;
+            d.ovf_n = d.ovf_room_base + room_off.back() + 1u;
+            if ((rc = dev_alloc(c, &d.ovf, (size_t)d.ovf_n))) return rc;
+            HIP_TRY(c, hipMemset(d.ovf, 0, sizeof(uint32_t) * (size_t)d.ovf_n));
         }
+        d.n_wrk_idx = (uint32_t)wrk_idx.size(); d.n_room_idx = (uint32_t)room_idx.size();
         d.big_qcap = d.items_cap / SUBQ;             // (a slot is listed at most once a chunk, and there are at most items_cap of them)
         if ((rc = dev_alloc(c, &d.big_list, (size_t)d.big_qcap * SUBQ * 3u))) return rc;
         if ((rc = dev_alloc(c, &d.used_pref, CHUNK_WAVES_MAX + 1u))) return rc;
+        HIP_TRY(c, hipMemset(d.big_list, 0, sizeof(uint32_t) * (size_t)d.big_qcap * SUBQ * 3u));
+        HIP_TRY(c, hipMemset(d.used_pref, 0, sizeof(uint32_t) * (CHUNK_WAVES_MAX + 1u)));
         if ((rc = dev_alloc(c, &d.pair_cnt, 16384u))) return rc;
         if ((rc = dev_alloc(c, &d.used_cnt, 16384u))) return rc;
         HIP_TRY(c, hipMemset(d.used_cnt, 0, sizeof(uint32_t) * 16384u));
@@ -404,6 +435,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         HIP_TRY(c, hipMemset(d.pair_cnt, 0, sizeof(uint32_t) * 16384u));
         d.newexp_cap = N / SUBQ + 1u;                 // citizens with the same id & 63: nobody is listed twice in a chunk
         if ((rc = dev_alloc(c, &d.newexp, (size_t)d.newexp_cap * SUBQ))) return rc;
+        HIP_TRY(c, hipMemset(d.newexp, 0, sizeof(uint32_t) * (size_t)d.newexp_cap * SUBQ));
         if ((rc = dev_alloc(c, &d.cursor, (size_t)EXP_ROWS * FREE_MAX))) return rc;
         HIP_TRY(c, hipMemset(d.hkey, 0xFF, sizeof(unsigned long long) * cap));
         HIP_TRY(c, hipMemset(d.vec, 0, sizeof(uint32_t) * (size_t)cap * FREE_MAX));
@@ -462,6 +494,8 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if ((rc = dev_upload(c, &d.shared_of_room, of_r.data(), of_r.size()))) return rc;
         if ((rc = dev_alloc(c, &d.xv, XV_HEADER + (size_t)FREE_MAX * (PLAN_W / 32u)))) return rc;
         if ((rc = dev_alloc(c, &d.xc, FREE_MAX + 2u))) return rc;
+        if ((rc = dev_alloc(c, &d.xe, 2))) return rc;
+        HIP_TRY(c, hipMemset(d.xe, 0, sizeof(uint32_t) * 2u));
         HIP_TRY(c, hipMemset(d.xv, 0, sizeof(uint32_t) * (XV_HEADER + (size_t)FREE_MAX * (PLAN_W / 32u))));
         HIP_TRY(c, hipMemset(d.xc, 0, sizeof(uint32_t) * (FREE_MAX + 2u)));
         d.rank = 0; d.world = 1; d.xs = nullptr;
@@ -934,6 +968,11 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -954,10 +993,16 @@ RcclApi &rccl()
     api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+    api.CommAbort = (decltype(api.CommAbort))dlsym(h, "ncclCommAbort");
+    api.Send = (decltype(api.Send))dlsym(h, "ncclSend");
+    api.Recv = (decltype(api.Recv))dlsym(h, "ncclRecv");
+    api.GroupStart = (decltype(api.GroupStart))dlsym(h, "ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))dlsym(h, "ncclGroupEnd");
     api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
     api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
-    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.AllGather && api.GetErrorString;
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.CommAbort && api.AllReduce && api.AllGather && api.Send && api.Recv &&
+             api.GroupStart && api.GroupEnd && api.GetErrorString;
     return api;
 }
 
@@ -1003,18 +1048,52 @@ int exchange_gather(esim_ctx_impl *c, int which, uint32_t *buf, size_t per_rank)
     return exchange_buf(c, which, buf, per_rank * (size_t)c->comm_world);
 }
 
-// what the exchange of sharded chunks needs once the number of ranks is known
+int wait_stream(esim_ctx_impl *c);
+
+// what the exchange of sharded chunks needs once the number of ranks is known; and the ranks' shards are checked against each
+// other -- one world (n_citizens_global, shared tables of the same size), rank r holding the r-th stretch of the global
+// citizen ids -- with one small all-reduce: a communicator over shards that do not belong together would run without an
+// error and give wrong records.
 int comm_buffers(esim_ctx_impl *c)
 {
     if (!c->uploaded) return fail(c, ESIM_ESTATE, "esim_comm_init: upload the population first");
     HIP_TRY(c, hipSetDevice(c->P.device));
     Dev &d = c->d;
+    int rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (d.xs) { dev_free(c, d.xs); d.xs = nullptr; }
+    if (c->xr) { dev_free(c, c->xr); c->xr = nullptr; c->xr_n = 0; }
     d.rank = (uint32_t)c->comm_rank; d.world = (uint32_t)c->comm_world;
     const size_t n = (size_t)d.world * (1u + 3u * (size_t)XS_CAP_MAX);
     d.xs_cap = 4096u;
-    int rc;
+    if (const char *e = std::getenv("ESIM_XS_CAP")) d.xs_cap = (uint32_t)std::min<long>(XS_CAP_MAX, std::max<long>(1, std::atol(e)));   // (tests: a segment that has to grow)
     if ((rc = dev_alloc(c, &d.xs, n))) return rc;
     HIP_TRY(c, hipMemset(d.xs, 0, sizeof(uint32_t) * n));
+    // the layout check
+    const uint32_t W = d.world;
+    std::vector<uint32_t> rows((size_t)W * 5u, 0u);
+    uint32_t *mine = &rows[(size_t)d.rank * 5u];
+    mine[0] = d.id_base; mine[1] = d.n; mine[2] = d.n_global; mine[3] = d.n_shared_bld; mine[4] = d.n_shared_room;
+    uint32_t *dv = nullptr;
+    if ((rc = dev_alloc(c, &dv, rows.size()))) return rc;
+    HIP_TRY(c, hipMemcpy(dv, rows.data(), sizeof(uint32_t) * rows.size(), hipMemcpyHostToDevice));
+    rc = exchange_buf(c, 8, dv, rows.size());
+    if (!rc) rc = wait_stream(c);
+    if (!rc && hipMemcpy(rows.data(), dv, sizeof(uint32_t) * rows.size(), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(c, ESIM_ENODEVICE, "esim_comm_init: read-back of the layout check failed");
+    dev_free(c, dv);
+    if (rc) return rc;
+    uint64_t next = 0;
+    for (uint32_t r = 0; r < W; ++r) {
+        const uint32_t *q = &rows[(size_t)r * 5u];
+        if (q[2] != d.n_global || q[3] != d.n_shared_bld || q[4] != d.n_shared_room || q[0] != next) {
+            char msg[256];
+            std::snprintf(msg, sizeof msg, "esim_comm_init: rank %u holds citizens [%u, %u) of %u with %u / %u shared buildings / rooms -- not shard %u of the world this rank's shard belongs to "
+                          "(expected ids from %llu, %u citizens in all, %u / %u shared)", r, q[0], q[0] + q[1], q[2], q[3], q[4], r, (unsigned long long)next, d.n_global, d.n_shared_bld, d.n_shared_room);
+            return fail(c, ESIM_EINVAL, msg);
+        }
+        next += q[1];
+    }
+    if (next != d.n_global) return fail(c, ESIM_EINVAL, "esim_comm_init: the ranks' shards do not add up to n_citizens_global (world size differs from the number of shards)");
     return ESIM_OK;
 }
 
@@ -1024,6 +1103,53 @@ int exchange(esim_ctx_impl *c, int which)
     uint32_t *buf = which == 2 ? d.xf : which ? d.xb : d.xa;
     const size_t n = which == 2 ? c->xf_n + 1 : which ? c->xb_n : c->xa_n;
     return exchange_buf(c, which, buf, n);
+}
+
+// The host's wait for a stream that holds RCCL collectives has a deadline: a peer that died or left (a crash, an exchange that
+// failed on its side) would otherwise leave this rank inside a collective for ever.  On expiry the communicator is aborted
+// (ncclCommAbort ends the collective kernels), the context is left without one, and the call fails with ESIM_ETIMEDOUT -- the
+// caller is expected to exit with an error, as the reference does when step() fails (run/src/main.rs:306-308).
+int wait_stream(esim_ctx_impl *c)
+{
+    if (!c->nccl) { HIP_TRY(c, hipStreamSynchronize(c->stream)); return ESIM_OK; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipSuccess) return ESIM_OK;
+        if (e != hipErrorNotReady) return fail(c, ESIM_ENODEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > c->comm_timeout_s) {
+            (void)rccl().CommAbort(c->nccl);
+            c->nccl = nullptr;
+            char msg[200];
+            std::snprintf(msg, sizeof msg, "rank %d: no progress on the stream for %.1f s inside a sharded run (a peer left or died); the RCCL communicator was aborted",
+                          c->comm_rank, waited);
+            return fail(c, ESIM_ETIMEDOUT, msg);
+        }
+        if (waited > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(waited > 0.1 ? 1000 : 20));
+    }
+}
+
+// Every read-back of the control block in a sharded run: the shards' error fields are summed first (k_status_pack ->
+// all-reduce -> k_status_unpack), so every rank sees any rank's device-side error in the same collective and takes the same
+// return decision from the same word.
+int sync_status(esim_ctx_impl *c, bool ex, Ctrl *h)
+{
+    Dev &d = c->d;
+    int rc;
+    hipLaunchKernelGGL(k_status_pack, dim3(1), dim3(64), 0, c->stream, d);
+    if (ex && (rc = exchange_buf(c, 7, d.xe, 2))) return rc;
+    hipLaunchKernelGGL(k_status_unpack, dim3(1), dim3(64), 0, c->stream, d);
+    HIP_TRY(c, hipMemcpyAsync(h, d.ctrl, sizeof *h, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = wait_stream(c))) return rc;
+    if (h->peer_error) {
+        const uint32_t code = err_decode(h->peer_error);
+        char msg[240];
+        std::snprintf(msg, sizeof msg, "device-side error %d on at least one shard (S underflow / vaccination window exhausted / a chunk table overflowed); every rank returns it",
+                      -(int)code);
+        return fail(c, -(int)code, msg);
+    }
+    return ESIM_OK;
 }
 
 }  // namespace
@@ -1042,7 +1168,8 @@ extern "C" int esim_comm_unique_id(void *out, size_t cap)
 extern "C" int esim_comm_init_rccl(esim_ctx *ctx, const void *unique_id, size_t id_bytes, int rank, int world)
 {
     esim_ctx_impl *c = CTX(ctx);
-    if (!c || !unique_id || id_bytes < sizeof(ncclUniqueId) || rank < 0 || rank >= world) return fail(c, ESIM_EINVAL, "esim_comm_init_rccl: bad argument");
+    if (!c || !unique_id || id_bytes < sizeof(ncclUniqueId) || rank < 0 || rank >= world || world > (int)ERR_MAX_WORLD) return fail(c, ESIM_EINVAL, "esim_comm_init_rccl: bad argument (0 <= rank < world <= 31)");
+    if (!c->uploaded) return fail(c, ESIM_ESTATE, "esim_comm_init_rccl: upload the population first");
     if (!rccl().ok) return fail(c, ESIM_ENODEVICE, "librccl could not be loaded");
     HIP_TRY(c, hipSetDevice(c->P.device));
     if (c->nccl) { rccl().CommDestroy(c->nccl); c->nccl = nullptr; }
@@ -1051,16 +1178,40 @@ extern "C" int esim_comm_init_rccl(esim_ctx *ctx, const void *unique_id, size_t 
     ncclResult_t r = rccl().CommInitRank(&c->nccl, world, id, rank);
     if (r != ncclSuccess) { c->nccl = nullptr; return fail(c, ESIM_ENODEVICE, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r)); }
     c->comm_rank = rank; c->comm_world = world; c->comm_fn = nullptr;
-    return comm_buffers(c);
+    const int rc = comm_buffers(c);
+    if (rc) { comm_release(c); c->comm_rank = 0; c->comm_world = 1; c->d.rank = 0; c->d.world = 1; }
+    return rc;
 }
 
 extern "C" int esim_comm_init_callback(esim_ctx *ctx, esim_allreduce_fn fn, void *user, int rank, int world)
 {
     esim_ctx_impl *c = CTX(ctx);
-    if (!c || !fn || rank < 0 || rank >= world) return fail(c, ESIM_EINVAL, "esim_comm_init_callback: bad argument");
+    if (!c || !fn || rank < 0 || rank >= world || world > (int)ERR_MAX_WORLD) return fail(c, ESIM_EINVAL, "esim_comm_init_callback: bad argument (0 <= rank < world <= 31)");
+    if (!c->uploaded) return fail(c, ESIM_ESTATE, "esim_comm_init_callback: upload the population first");
     if (c->nccl) { rccl().CommDestroy(c->nccl); c->nccl = nullptr; }
     c->comm_fn = fn; c->comm_user = user; c->comm_rank = rank; c->comm_world = world;
-    return comm_buffers(c);
+    const int rc = comm_buffers(c);
+    if (rc) { c->comm_fn = nullptr; c->comm_rank = 0; c->comm_world = 1; c->d.rank = 0; c->d.world = 1; }
+    return rc;
+}
+
+extern "C" int esim_comm_set_timeout(esim_ctx *ctx, double seconds)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !(seconds > 0.0)) return fail(c, ESIM_EINVAL, "esim_comm_set_timeout: seconds must be positive");
+    c->comm_timeout_s = seconds;
+    return ESIM_OK;
+}
+
+extern "C" int esim_debug_inject_error(esim_ctx *ctx, int code)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded || code > -1 || code < -6) return fail(c, ESIM_EINVAL, "esim_debug_inject_error: code must be one of the ESIM_E* values");
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint32_t v = (uint32_t)(-code);
+    HIP_TRY(c, hipMemcpy(&c->d.ctrl->error, &v, sizeof v, hipMemcpyHostToDevice));
+    return ESIM_OK;
 }
 
 extern "C" int esim_comm_stats(esim_ctx *ctx, uint64_t *collectives)
@@ -1120,7 +1271,7 @@ int run_coupled_steps(esim_ctx_impl *c, uint32_t n, bool ex)
         if ((rc = enqueue_exposures(c, tk))) return rc;
         if (ex && (rc = exchange(c, 1))) return rc;
         if ((rc = enqueue_finish(c, tk))) return rc;
-        if ((s & 255u) == 255u) HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if ((s & 255u) == 255u && (rc = wait_stream(c))) return rc;
     }
     c->shard_step_steps += n;
     return ESIM_OK;
@@ -1142,21 +1293,25 @@ extern "C" int esim_run_sharded(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_don
     HIP_TRY(c, hipSetDevice(c->P.device));
     Dev &d = c->d;
     const uint32_t first = c->host_t;
+    // no early stop here (a shard's local census says nothing about the disease elsewhere, and shards that stopped at
+    // different steps would issue different collectives): a flag an earlier esim_run left on the device is cleared
+    static const uint32_t zero = 0u;
+    HIP_TRY(c, hipMemcpyAsync(&d.ctrl->stop_when_done, &zero, sizeof zero, hipMemcpyHostToDevice, c->stream));
     // (a communicator on an unsharded context -- one rank -- still makes its collectives: the sums over one rank change nothing,
     // which is how the RCCL path is exercised on a one-GPU box)
     const bool ex = d.n_shards > 1 || c->nccl || c->comm_fn;
     const bool chunks = ex && d.xs && c->pipeline && c->time_parallel && d.items_cap > 0;
     std::vector<std::pair<uint32_t, uint32_t>> local_ranges;     // [first step, count) whose records hold this shard's census
     uint32_t remaining = n_steps, stall = 0;
+    Ctrl h;
     while (remaining > 0) {
         if (chunks && (!c->elig_seen || c->vax_chunks)) {
             const uint32_t t_first = c->host_t, limit_t = t_first + remaining - 1u;
             const uint32_t bursts = stall ? 1u : std::min<uint32_t>((remaining + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n + (c->elig_seen ? 1u : 0u), 4u);
             for (uint32_t g = 0; g < bursts; ++g) if ((rc = enqueue_sharded_chunk(c, limit_t, c->elig_seen))) return rc;
-            Ctrl h;
-            HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (h.error) return fail_dev(c, h.error);
+            // every rank reads the same decision words: steps advanced (all shards run a chunk or none does), the summed error
+            // fields, the gathered segment need
+            if ((rc = sync_status(c, ex, &h))) return rc;
             const uint32_t done = h.t - t_first;
             c->host_t = h.t; remaining -= done;
             c->shard_chunk_steps += done;
@@ -1173,23 +1328,26 @@ extern "C" int esim_run_sharded(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_don
         const uint32_t k = std::min<uint32_t>(remaining, (!chunks || (c->elig_seen && !c->vax_chunks)) ? remaining : (stall <= 1u ? 1u : (stall <= 3u ? 8u : (uint32_t)c->xf_n)));
         if ((rc = run_coupled_steps(c, k, ex))) return rc;
         remaining -= k;
-        Ctrl h;
-        HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (h.error) return fail_dev(c, h.error);
+        if ((rc = sync_status(c, ex, &h))) return rc;
         c->elig_seen = h.have_elig != 0u;
     }
     // the records of the steps drawn as chunks: this shard's census -> everybody's
     for (auto &rg : local_ranges) {
         const size_t n = (size_t)rg.second * XR_FIELDS;
-        if (n > c->xr_n) { if ((rc = dev_alloc(c, &c->xr, n))) return rc; c->xr_n = n; }
+        if (n > c->xr_n) {
+            if ((rc = wait_stream(c))) return rc;                        // (the buffer being replaced may still be in use)
+            if (c->xr) dev_free(c, c->xr);
+            c->xr = nullptr; c->xr_n = 0;
+            if ((rc = dev_alloc(c, &c->xr, n))) return rc;
+            c->xr_n = n;
+        }
         hipLaunchKernelGGL(k_records_pack, dim3(grid_for(rg.second, TPB, 64)), dim3(TPB), 0, c->stream, d, rg.first, rg.second, c->xr);
         if (ex && (rc = exchange_buf(c, 6, c->xr, n))) return rc;
         hipLaunchKernelGGL(k_records_unpack, dim3(grid_for(rg.second, TPB, 64)), dim3(TPB), 0, c->stream, d, rg.first, rg.second, c->xr);
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if ((rc = wait_stream(c))) return rc;
     if (n_done) *n_done = c->host_t - first;
-    return device_error(c);
+    return ESIM_OK;
 }
 
 extern "C" int esim_shard_stats(esim_ctx *ctx, uint64_t *chunk_steps, uint64_t *coupled_steps)
@@ -1481,12 +1639,31 @@ extern "C" int esim_download_exposure_log(esim_ctx *ctx, uint32_t *citizen, uint
 namespace {
 struct CkptHeader {
     uint32_t magic, version, n, n_global, id_base, max_steps, host_t, log_len;
-    uint32_t exposed_time, infected_time, vaccination_rate, bus_capacity, start_hour, end_hour, ctrl_bytes, reserved;
+    uint32_t exposed_time, infected_time, vaccination_rate, bus_capacity, start_hour, end_hour, ctrl_bytes, layout_id;
     uint64_t seed;
     uint64_t pop_hash;
     double thresholds[6];
 };
-const uint32_t CKPT_MAGIC = 0x4D495345u /* "ESIM" */, CKPT_VERSION = 2u;
+const uint32_t CKPT_MAGIC = 0x4D495345u /* "ESIM" */, CKPT_VERSION = 3u;
+
+// What a checkpoint's bytes mean depends on how this build lays the state out: the citizen word's fields, the exposure-step
+// bias and sentinels, the control block's fields.  The header carries a hash of all of that; a checkpoint written by a build
+// with another layout (an older library, a diagnostics build that moved a field) is refused instead of reinterpreted.
+constexpr uint32_t layout_mix(uint32_t h, uint32_t v) { return (h ^ v) * 16777619u; }
+constexpr uint32_t ckpt_layout_id()
+{
+    uint32_t h = 2166136261u;
+    const uint32_t parts[] = {
+        CKPT_VERSION, (uint32_t)sizeof(Ctrl), (uint32_t)sizeof(esim_step_result), (uint32_t)sizeof(Decision),
+        (uint32_t)offsetof(Ctrl, t), (uint32_t)offsetof(Ctrl, lockdown), (uint32_t)offsetof(Ctrl, mask), (uint32_t)offsetof(Ctrl, vacc_active),
+        (uint32_t)offsetof(Ctrl, have_elig), (uint32_t)offsetof(Ctrl, trigger_step), (uint32_t)offsetof(Ctrl, elig_count), (uint32_t)offsetof(Ctrl, at_work),
+        (uint32_t)offsetof(Ctrl, bus_dir), (uint32_t)offsetof(Ctrl, steps_done), (uint32_t)offsetof(Ctrl, error), (uint32_t)offsetof(Ctrl, n_susceptible),
+        (uint32_t)offsetof(Ctrl, n_vaccinated), (uint32_t)offsetof(Ctrl, log_len), (uint32_t)offsetof(Ctrl, chunk_pairs), (uint32_t)offsetof(Ctrl, peer_error),
+        CW_TE_SHIFT, CW_BUS_EXPOSED, CW_FLAGS, CW_VAX_SHIFT, CW_VAX_MASK, CW_PLAN_SKIP, TE_SUSCEPTIBLE, TE_VACCINATED, TE_RECOVERED, TE_BIAS, TE_SLOTS,
+        FL_USES_PT, FL_MASK_COMPLIANT, FL_SAME_AREA, FL_WORK_SCHOOL, FL_HAS_WORK, FL_BIG_ROUTE, MARK_SLOTS, FREE_MAX };
+    for (uint32_t v : parts) h = layout_mix(h, v);
+    return h;
+}
 
 void ckpt_header(const esim_ctx_impl *c, const Ctrl &h, CkptHeader *o)
 {
@@ -1494,7 +1671,7 @@ void ckpt_header(const esim_ctx_impl *c, const Ctrl &h, CkptHeader *o)
     o->magic = CKPT_MAGIC; o->version = CKPT_VERSION; o->n = c->d.n; o->n_global = c->d.n_global; o->id_base = c->d.id_base;
     o->max_steps = c->P.max_steps; o->host_t = c->host_t; o->log_len = h.log_len;
     o->exposed_time = c->P.exposed_time; o->infected_time = c->P.infected_time; o->vaccination_rate = c->P.vaccination_rate;
-    o->bus_capacity = c->P.bus_capacity; o->start_hour = c->P.start_hour; o->end_hour = c->P.end_hour; o->ctrl_bytes = (uint32_t)sizeof(Ctrl);
+    o->bus_capacity = c->P.bus_capacity; o->start_hour = c->P.start_hour; o->end_hour = c->P.end_hour; o->ctrl_bytes = (uint32_t)sizeof(Ctrl); o->layout_id = ckpt_layout_id();
     o->seed = c->P.seed; o->pop_hash = c->pop_hash;
     const double th[6] = { c->P.exposure_chance, c->P.mask_effectiveness, c->P.lockdown_threshold, c->P.vaccination_threshold,
                            c->P.mask_pt_threshold, c->P.mask_everywhere_threshold };
@@ -1561,6 +1738,7 @@ extern "C" int esim_checkpoint_restore(esim_ctx *ctx, const void *buf, size_t by
     std::memset(&zero, 0, sizeof zero);
     ckpt_header(c, zero, &mine);
     if (k.magic != CKPT_MAGIC || k.version != CKPT_VERSION || k.ctrl_bytes != sizeof(Ctrl)) return fail(c, ESIM_EINVAL, "esim_checkpoint_restore: not a checkpoint of this library version");
+    if (k.layout_id != ckpt_layout_id()) return fail(c, ESIM_EINVAL, "esim_checkpoint_restore: the checkpoint was written by a build with another state layout (citizen word / control block); it is refused, not reinterpreted");
     if (k.n != mine.n || k.n_global != mine.n_global || k.id_base != mine.id_base || k.seed != mine.seed || k.exposed_time != mine.exposed_time ||
         k.infected_time != mine.infected_time || k.vaccination_rate != mine.vaccination_rate || k.bus_capacity != mine.bus_capacity ||
         k.start_hour != mine.start_hour || k.end_hour != mine.end_hour || k.pop_hash != mine.pop_hash || std::memcmp(k.thresholds, mine.thresholds, sizeof k.thresholds) != 0)
@@ -1578,7 +1756,7 @@ extern "C" int esim_checkpoint_restore(esim_ctx *ctx, const void *buf, size_t by
         return fail(c, ESIM_EINVAL, "esim_checkpoint_restore: the control block does not match the checkpoint's header (corrupt file)");
     h.chunk_ok = 0; h.chunk_parallel = 0; h.chunk_done = 0; h.n_items = 0; h.n_newexp = 0; h.n_units = 0; h.unit_next = 0;
     h.n_route_pairs = 0; h.n_route_pairs_big = 0; h.prev_n_items = 0; h.prev_per_wave = 0; h.items_per_wave = 0; h.small_done = 0;
-    h.free_base = 0; h.n_riders = 0;
+    h.free_base = 0; h.n_riders = 0; h.peer_error = 0;
     for (int z = 0; z < 5; ++z) h.counts[z] = 0;
     // marks of the last step are only ever cleared, never read, by the step after it: start without them
     for (uint32_t z = 0; z < MARK_SLOTS; ++z) { h.n_touched_bld[z] = 0; h.n_touched_room[z] = 0; h.n_touched_route[z] = 0; h.n_touched_route_big[z] = 0; }

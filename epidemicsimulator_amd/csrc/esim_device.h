@@ -104,7 +104,19 @@ struct Ctrl {
     uint32_t vax_planned, prev_planned; // steps the plan of the chunk in preparation / being finished covers (>= the chunk's length)
     uint32_t xs_need;           // sharded chunks: the most commuter records any shard wanted to send for the chunk last prepared
     uint32_t vax_fail;          // sharded plans: steps whose candidates beyond the exchanged window would have been needed (plan void)
+    uint32_t peer_error;        // sharded runs: the error fields of ALL shards, summed (ERR_FIELD): every rank takes its return code
+                                // from this word, so that all leave esim_run_sharded together (k_status_unpack)
 };
+
+// A rank's sticky error (1..6 = -ESIM_E*) as a 5-bit field of a word the shards SUM: field c-1 counts the shards that raised
+// code c (at most 31 shards).  Every shard decodes the lowest code present, i.e. the same one.
+#define ERR_FIELD(code) ((code) ? 1u << (5u * (((code) < 1u || (code) > 6u ? 6u : (code)) - 1u)) : 0u)
+#define ERR_MAX_WORLD 31u
+static inline __host__ __device__ uint32_t err_decode(uint32_t word)
+{
+    for (uint32_t c = 1u; c <= 6u; ++c) if ((word >> (5u * (c - 1u))) & 31u) return c;
+    return word ? 6u : 0u;
+}
 
 // A deferred unit of a long member list: UNIT_PAIRS (member, marked step) pairs from pair p_lo on.  code = kind << 30 | p_lo
 // (UNIT_NOOP: skip); m_first = the member its first pair belongs to.
@@ -171,7 +183,9 @@ struct Dev {
     // room's to ovf[ovf_room_base + room_off[r] ...); k_chunk_fold sums them into `vec` before the draw pass
     const uint32_t *ovf_off;    // [n_bld + 1] res_off + wrk_off
     uint32_t ovf_room_base;     // ovf_off[n_bld]
-    uint32_t *ovf;              // [ovf_room_base + room_off[n_room]]
+    uint32_t *ovf;              // [ovf_n = ovf_room_base + room_off[n_room] + 1]
+    uint32_t ovf_n;
+    uint32_t n_wrk_idx, n_room_idx;   // lengths of wrk_idx / room_idx (what a member range read from a chunk table is checked against)
     uint32_t *big_list;         // [SUBQ][big_qcap][3] slots with records in `ovf`, where those start and how many fit, listed by the first
                                 // to put one there; 64 lists by listing wavefront & 63, lengths in hot[HOT_BIG ...]
     uint32_t big_qcap;
@@ -216,7 +230,8 @@ struct Dev {
     uint32_t *xv;                       // [XV_HEADER + FREE_MAX * PLAN_W / 32] liveness of every step's first PLAN_W vaccination candidates
     uint32_t *xs;                       // [world][1 + 3 * xs_cap] Infected commuters to shared buildings: (citizen word, shared building, shared room | -1)
     uint32_t xs_cap;                    // records per shard in this chunk's exchange
-    uint32_t *xc;                       // [FREE_MAX + 2] steps of the chunk with a cut (k_chunk_count), error flag
+    uint32_t *xc;                       // [FREE_MAX + 2] steps of the chunk with a cut (k_chunk_count)
+    uint32_t *xe;                       // [2] status exchange: [0] error fields (ERR_FIELD), [1] shards that are finished
     const int32_t *shared_of_bld, *shared_of_room;   // [n_bld], [n_room]: index into the shared tables, -1 when not shared
 #ifdef ESIM_WAVE_PROFILE
     uint32_t *prof_buf;                 // diagnostics build only: [wavefronts][16] timers of the last chunk (tools/wave_profile.py)

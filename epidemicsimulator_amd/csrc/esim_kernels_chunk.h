@@ -451,7 +451,8 @@ __global__ __launch_bounds__(128) void k_shard_prep(Dev d, uint32_t max_ahead, u
     }
     ctrl->xs_need = 0u;
     for (uint32_t r = 0; r < d.world; ++r) ctrl->xs_need = max(ctrl->xs_need, d.xs[(size_t)r * (1u + 3u * d.xs_cap)]);
-    const bool fits = d.xf[d.xf_n] == 0u && !overflow &&
+    // (a shard in a device-side error state makes the chunk a no-op on EVERY shard: the word is summed)
+    const bool fits = d.xf[d.xf_n] == 0u && !overflow && !ctrl->error && !ctrl->finished &&
                       ((unsigned long long)ctrl->chunk_pairs + n_remote) * 4ull + 65536ull <= (unsigned long long)d.items_cap;
     d.xf[d.xf_n] = fits ? 0u : 1u;
     if (ctrl->vax_chunk && !ctrl->vax_fail) {
@@ -907,8 +908,11 @@ __global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
         const uint32_t mine = g + lane * step;
         if (mine < n_list) {
             slot_l = bl[3u * mine]; base_l = bl[3u * mine + 1u];
-            const uint32_t state = d.slot_state[slot_l];
-            n_ov_l = min((state > ITEM_RECS && state < SLOT_COUNTERS_ONLY) ? state - ITEM_RECS : 0u, bl[3u * mine + 2u]);
+            const uint32_t cap_l = bl[3u * mine + 2u];
+            if (slot_l < d.hcap && base_l <= d.ovf_n && cap_l <= d.ovf_n - base_l) {
+                const uint32_t state = d.slot_state[slot_l];
+                n_ov_l = min((state > ITEM_RECS && state < SLOT_COUNTERS_ONLY) ? state - ITEM_RECS : 0u, cap_l);
+            } else { slot_l = 0u; base_l = 0u; ctrl->error = (uint32_t)(-ESIM_ERANGE); }   // (no list entry k_chunk_marks wrote looks like this)
         }
         const uint32_t m = min(64u, (n_list - g + step - 1u) / step);
         // ... then slot by slot, lanes = records; the first 64 records of eight slots are fetched together
@@ -1175,7 +1179,7 @@ __device__ __forceinline__ uint32_t fetch_item(const Dev &d, uint32_t v, uint32_
 __device__ __forceinline__ uint32_t fetch_slot(const Dev &d, uint32_t slot, uint32_t lane)
 {
     uint32_t x = 0u;
-    if (slot != ITEM_UNUSED) {
+    if (slot < d.hcap) {                                                       // (ITEM_UNUSED, or anything else that is no slot: nothing fetched)
         if (lane >= 8u && lane < 8u + ITEM_RECS) x = d.slot_iv[(size_t)slot * SLOT_IV_STRIDE + (lane - 8u)];
         else if (lane == LANE_STATE) x = d.slot_state[slot];
     }
@@ -1210,11 +1214,26 @@ __device__ __forceinline__ ItemFetch decode_item(const Dev &d, uint32_t x, uint3
     ItemFetch f;
     f.slot = FX(x, LANE_HSLOT); f.id = FX(x, 0); f.a_lo = FX(x, 1); f.a_hi = FX(x, 2); f.b_lo = FX(x, 3); f.b_hi = FX(x, 4); f.aux = FX(x, 5); f.link = FX(x, 6);
     f.c0 = 0u; f.c1 = 0u;
-    if (f.slot != ITEM_UNUSED) {
+    if (f.slot < d.hcap) {
         item_counts(d, x, f.slot, lane, n, AW, BUS, f.c0, f.c1);
         iv_count(FX(x, 7), lane, AW, BUS, f.c0, f.c1);
     }
     return f;
+}
+
+// What a chunk table says is checked against the capacities before it is used as an index: a table that does not hold what
+// k_chunk_marks writes (a diagnostics build that leaves a write out, a defect) ends in ESIM_ERANGE, not in a memory fault.
+__device__ __forceinline__ bool item_ok(const Dev &d, const ItemFetch &it)
+{
+    if (it.slot >= d.hcap) return false;
+    if (it.id < d.n_bld) return it.a_lo <= it.a_hi && it.a_hi <= d.n && it.b_lo <= it.b_hi && it.b_hi <= d.n_wrk_idx;
+    if (it.id < d.n_bld + d.n_room) return it.a_lo <= it.a_hi && it.a_hi <= d.n_room_idx && (it.link == 0xFFFFFFFFu || it.link < d.hcap);
+    return true;
+}
+__device__ __forceinline__ bool unit_ok(const Dev &d, uint32_t kind, uint32_t slot, uint32_t link, uint32_t lo, uint32_t n_mem)
+{
+    const uint32_t len = kind == 2u ? d.n_room_idx : kind == 1u ? d.n_wrk_idx : d.n;
+    return kind <= 2u && slot < d.hcap && (link == 0xFFFFFFFFu || link < d.hcap) && lo <= len && n_mem <= len - lo;
 }
 
 #define PAIR_SPREAD 1237u
@@ -1266,8 +1285,8 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     bool have = false;
     if (lane < K) {
         const uint32_t src = (wave + n_waves - (uint32_t)(((unsigned long long)lane * PAIR_SPREAD) % n_waves)) % n_waves;
-        have = lane < d.pair_cnt[src];
         code_l = d.route_pairs[(size_t)src * K + lane];                       // in bounds whether or not the pair exists
+        have = lane < d.pair_cnt[src] && (code_l >> 7) < d.n_routes && (code_l & 127u) < n;
     }
     for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
     for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
@@ -1295,6 +1314,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
         const uint32_t pq0 = PROF_NOW();
         const ItemFetch it = decode_item(d, x, lane, n, AW, BUS);
         if (it.slot == ITEM_UNUSED) continue;
+        if (!item_ok(d, it)) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); continue; }
         if (it.id >= route_base) continue;
         const uint32_t pi0 = PROF_NOW();
         pst[0] += pi0 - pq0;
@@ -1347,8 +1367,8 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
             have = false;
             if (kk < K) {
                 const uint32_t src = (wave + n_waves - (uint32_t)(((unsigned long long)kk * PAIR_SPREAD) % n_waves)) % n_waves;
-                have = kk < d.pair_cnt[src];
                 code_l = d.route_pairs[(size_t)src * K + kk];
+                have = kk < d.pair_cnt[src] && (code_l >> 7) < d.n_routes && (code_l & 127u) < n;
             }
             if (have) { const uint32_t r = code_l >> 7; off_l = d.route_off[r]; sz_l = d.route_off[r + 1] - off_l; }
         }
@@ -1435,7 +1455,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
     auto unit_words = [&](uint32_t q) -> uint32_t { return lane < 8u ? q_words[(size_t)q * 8u + lane] : 0u; };
     auto member_id = [&](uint32_t u) -> uint32_t {
         const uint32_t code = FX(u, 4), kind = code >> 30, lo = FX(u, 2), n_mem = FX(u, 3), mf = FX(u, 6);
-        if (code == UNIT_NOOP || mf + lane >= n_mem) return 0u;
+        if (code == UNIT_NOOP || mf + lane >= n_mem || !unit_ok(d, kind, FX(u, 0), FX(u, 1), lo, n_mem)) return 0u;
         const uint32_t *idx = kind == 2u ? d.room_idx : kind == 1u ? d.wrk_idx : d.res_idx;
         return idx ? idx[lo + mf + lane] : lo + mf + lane;
     };
@@ -1456,6 +1476,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
         const uint32_t pui = PROF_NOW();
         ++pu_n;
         const uint32_t kind = code >> 30, p_lo = code & 0x3FFFFFFFu, slot = FX(u, 0), link = FX(u, 1), lo = FX(u, 2), n_mem = FX(u, 3), own = FX(u, 5), mf = FX(u, 6);
+        if (!unit_ok(d, kind, slot, link, lo, n_mem)) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); continue; }
         const uint32_t mw = (mf + lane < n_mem) ? d.cit[mid] : 0u;
         uint32_t c0, c1;
         item_counts(d, xs, slot, lane, n, AW, BUS, c0, c1);
@@ -1482,6 +1503,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
     for (uint32_t q = blockIdx.x; q < n_pairs; q += gridDim.x) {
         const uint32_t code = d.route_pairs_big[q], r = code >> 7, j = code & 127u;
+        if (r >= d.n_routes || j >= n) { if (threadIdx.x == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); continue; }   // (block-uniform)
         const uint32_t off = d.route_off[r], sz = d.route_off[r + 1] - off;
         const uint32_t s = t0 + j, mask = sm.dec[j].mask;
         for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
@@ -1532,6 +1554,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_count(Dev d)
     if (threadIdx.x == 0) s_cut = 0xFFFFFFFFu;
     __syncthreads();
     for (uint32_t i = tid / SUBQ; i < n_new; i += step) {
+        if (list[i] >= d.n) continue;
         const uint32_t w = d.cit[list[i]];
         const uint32_t j = CW_TE(w) - TE_BIAS - t0;
         if (j < FREE_MAX) atomicAdd(&e_cnt[2u * j + ((w & CW_BUS_EXPOSED) ? 1u : 0u)], 1u);
@@ -1584,6 +1607,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d)
         const uint32_t n_eff = ctrl->prev_n_eff;
         for (uint32_t i = tid / SUBQ; i < n_new; i += step) {
             const uint32_t m = list[i];
+            if (m >= d.n) continue;
             const uint32_t te = CW_TE(d.cit[m]);
             if (te - TE_BIAS - t0 < n_eff) d.log[d.log_off[te] + atomicAdd(&d.cursor[(blockIdx.x % EXP_ROWS) * FREE_MAX + te - TE_BIAS - t0], 1u)] = m;
             else {
@@ -1603,7 +1627,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d)
         const uint32_t w = i / per_wave, k = i - w * per_wave;
         if (k >= d.used_cnt[w]) continue;
         const uint32_t h = d.hitems[i];
-        if (h == ITEM_UNUSED) continue;
+        if (h >= d.hcap) continue;                                             // ITEM_UNUSED (or no slot at all)
         const uint32_t state = d.slot_state[h];
         if (state > ITEM_RECS && d.item_rec[i].id < d.n_bld + d.n_room)       // somebody spilled into the per-step counters
             for (uint32_t j = 0; j < FREE_MAX; ++j) d.vec[(size_t)h * FREE_MAX + j] = 0u;
@@ -1799,8 +1823,10 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
     const uint32_t *list = d.newexp + (size_t)r * d.newexp_cap;
     if (fused) {
         for (uint32_t i = tid / SUBQ; i < n_new; i += FIN_TPB / SUBQ) {
+            if (list[i] >= d.n) continue;
             const uint32_t w = d.cit[list[i]];
-            atomicAdd(&e_cnt[2u * (CW_TE(w) - TE_BIAS - t0) + ((w & CW_BUS_EXPOSED) ? 1u : 0u)], 1u);
+            const uint32_t j = CW_TE(w) - TE_BIAS - t0;
+            if (j < FREE_MAX) atomicAdd(&e_cnt[2u * j + ((w & CW_BUS_EXPOSED) ? 1u : 0u)], 1u);
         }
     } else if (tid < 2u * n) {
         // k_chunk_count made them, in EXP_ROWS rows by workgroup.  k_chunk_scatter's workgroups visit the same citizens as their
@@ -1842,8 +1868,9 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
     if (fused) {
         for (uint32_t i = tid / SUBQ; i < n_new; i += FIN_TPB / SUBQ) {
             const uint32_t m = list[i];
+            if (m >= d.n) continue;
             const uint32_t j = CW_TE(d.cit[m]) - TE_BIAS - t0;
-            d.log[lo_s[j] + atomicAdd(&cur_s[j], 1u)] = m;
+            if (j < FREE_MAX) d.log[lo_s[j] + atomicAdd(&cur_s[j], 1u)] = m;
         }
         // the ids each wavefront of k_chunk_marks handed out: thread t looks after the wavefronts t, t + 1024, ...; all loads
         // of a round are in flight together (this loop is nothing but memory latency)
@@ -1860,14 +1887,14 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) st[a][k] = h[a][k] != ITEM_UNUSED ? d.slot_state[h[a][k]] : 0u;
+                for (int k = 0; k < 4; ++k) st[a][k] = h[a][k] < d.hcap ? d.slot_state[h[a][k]] : 0u;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const uint32_t base = (w0 + (uint32_t)a * FIN_TPB) * per_wave;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t hs = h[a][k], state = st[a][k];
-                    if (hs == ITEM_UNUSED) continue;
+                    if (hs >= d.hcap) continue;
                     if (state > ITEM_RECS && d.item_rec[base + (uint32_t)k].id < d.n_bld + d.n_room)   // somebody spilled into the per-step counters
                         for (uint32_t j = 0; j < FREE_MAX; ++j) d.vec[(size_t)hs * FREE_MAX + j] = 0u;
                     d.hkey[hs] = HKEY_EMPTY;
@@ -1875,7 +1902,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
                 }
                 for (uint32_t k = 4u; k < used[a]; ++k) {                     // (more than four ids per wavefront: many Infected)
                     const uint32_t hs = d.hitems[base + k];
-                    if (hs == ITEM_UNUSED) continue;
+                    if (hs >= d.hcap) continue;
                     const uint32_t state = d.slot_state[hs];
                     if (state > ITEM_RECS && d.item_rec[base + k].id < d.n_bld + d.n_room)
                         for (uint32_t j = 0; j < FREE_MAX; ++j) d.vec[(size_t)hs * FREE_MAX + j] = 0u;

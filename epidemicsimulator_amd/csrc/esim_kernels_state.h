@@ -55,3 +55,16 @@ __global__ __launch_bounds__(TPB) void k_records_unpack(Dev d, uint32_t first, u
         d.records[first + i] = r;
     }
 }
+
+// Sharded runs: every host read-back of the control block is preceded by a SUM all-reduce of the shards' error fields, so that
+// every rank sees any rank's device-side error in the same collective and all leave esim_run_sharded together with the
+// same code (a rank that left alone would leave its peers inside their next collective).
+__global__ __launch_bounds__(64) void k_status_pack(Dev d)
+{
+    if (threadIdx.x == 0) { d.xe[0] = ERR_FIELD(d.ctrl->error); d.xe[1] = d.ctrl->finished ? 1u : 0u; }
+}
+
+__global__ __launch_bounds__(64) void k_status_unpack(Dev d)
+{
+    if (threadIdx.x == 0) { d.ctrl->peer_error |= d.xe[0]; if (d.xe[0] && !d.ctrl->error) d.ctrl->error = err_decode(d.xe[0]); }
+}

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(TPB) void k_pack_b(Dev d)
         const uint32_t eb = d.exp_step[2u * t], eu = d.exp_step[2u * t + 1u];
         d.xb[0] = eb; d.xb[1] = eu;
         d.xb[2] = trig ? ctrl->n_susceptible - eb - eu : ctrl->elig_count;
-        d.xb[3] = ctrl->error;
+        d.xb[3] = ERR_FIELD(ctrl->error);                                   // (summed over the shards: a field per code)
     }
     if (i < VACC_WINDOW) {
         bool live = false;
@@ -503,7 +503,7 @@ __device__ __forceinline__ void finish_phase(const Dev &d, Ctrl *ctrl, int shard
     __syncthreads();
     if (tid == 0) {
         const uint32_t exps = exp_bld + exp_bus;
-        if (sharded) ctrl->error |= d.xb[3];
+        if (sharded && d.xb[3]) { ctrl->peer_error |= d.xb[3]; if (!ctrl->error) ctrl->error = err_decode(d.xb[3]); }   // any shard's error is everybody's
         esim_step_result r;
         r.time_step = t;
         if (exps > cen[0]) ctrl->error = (uint32_t)(-ESIM_ESIM);          // citizen_exposed underflow, statistics.rs:275-287

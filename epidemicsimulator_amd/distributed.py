@@ -5,7 +5,9 @@ axis, the Output Areas (sim/src/simulator.rs:167).  Citizens live on the shard o
 whose members live on several shards is "shared", and the Infected standing in it are what crosses between the shards -- the
 commuter exchange of SURVEY.md 8(e).  Every step runs in three device phases around two small SUM all-reduces (include/esim.h,
 esim_run_sharded): A = census + Infected counts of the shared buildings / rooms, B = exposure totals, eligible count and the
-liveness bits of the step's vaccination candidates.  The collectives are issued by the library itself: over RCCL (xGMI) with
+liveness bits of the step's vaccination candidates -- or, wherever a chunk of steps can run on every shard, one round of
+exchanges per chunk.  A device-side error on any shard reaches every rank in those same collectives: all ranks
+raise the same EsimError from run() together; a peer that died shows as ESIM_ETIMEDOUT after the deadline.  The collectives are issued by the library itself: over RCCL (xGMI) with
 its own communicator, enqueued on the context's stream between its kernels; or, for tests that put several ranks on one GPU,
 through a callback into torch.distributed's gloo backend.  torch.distributed is otherwise only the launcher's rendezvous (it
 carries the RCCL unique id from rank 0 to the others)."""
@@ -47,13 +49,32 @@ def clean_cuts(pop, n_shards, slack=0.1):
     return np.maximum.accumulate(np.asarray(cuts, np.uint32))
 
 
+def exchange_unique_id(lib, dist, rank, group=None):
+    """Rank 0 makes the RCCL unique id (esim_comm_unique_id) and broadcasts it TOGETHER WITH whether that worked: a rank 0 that
+    raised before the broadcast would leave the other ranks inside it (and the caller's next collective mismatched).  Every
+    rank returns the 128 bytes or raises the same EsimError -- after the broadcast, so the ranks stay in step."""
+    uid = (C.c_uint8 * 128)()
+    status, text = 0, ""
+    if rank == 0:
+        status = int(lib.esim_comm_unique_id(uid, 128))
+        if status != 0:
+            msg = lib.esim_last_error(None)
+            text = msg.decode() if msg else ""
+    box = [(status, text, bytes(uid))]
+    dist.broadcast_object_list(box, src=0, group=group)
+    status, text, raw = box[0]
+    if status != 0:
+        raise _lib.EsimError(status, "rank 0 could not make the RCCL unique id (%s)" % text)
+    return raw
+
+
 class ShardedSimulator:
     """One rank of a sharded run.  Give either `whole_population` (cut here with `cuts`, default clean_cuts) or
     `shard_population` (already this rank's shard).  transport: "rccl" (the library's own communicator; the unique id
     travels over `group`) or "callback" (every exchange is a torch.distributed all_reduce on `group`, e.g. gloo)."""
 
     def __init__(self, whole_population=None, rank=0, world_size=1, params=None, device_index=0, group=None,
-                 shard_population=None, cuts=None, transport="rccl"):
+                 shard_population=None, cuts=None, transport="rccl", timeout_s=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -75,13 +96,11 @@ class ShardedSimulator:
         self.sharded = world_size > 1
         self.transport = transport if self.sharded else "none"
         self._steps = 0
+        if timeout_s is not None:          # deadline of the library's waits inside a sharded run (default 60 s)
+            _lib.check(self.lib.esim_comm_set_timeout(self._ctx, float(timeout_s)), self._ctx)
         if self.sharded and transport == "rccl":
-            uid = (C.c_uint8 * 128)()
-            if rank == 0:
-                _lib.check(self.lib.esim_comm_unique_id(uid, 128))
-            box = [bytes(uid)]
-            dist.broadcast_object_list(box, src=0, group=group)
-            buf = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            raw = exchange_unique_id(self.lib, dist, rank, group)      # every rank raises together when rank 0 could not make it
+            buf = (C.c_uint8 * 128).from_buffer_copy(raw)
             _lib.check(self.lib.esim_comm_init_rccl(self._ctx, buf, 128, rank, world_size), self._ctx)
         elif self.sharded:
             def allreduce(_user, _which, host_ptr, n):

@@ -32,6 +32,7 @@ extern "C" {
 #define ESIM_ESTATE     -4   /* call out of order (e.g. step before upload) */
 #define ESIM_ERANGE     -5   /* step budget / encoding range exceeded */
 #define ESIM_ESIM       -6   /* the reference's own error path (S underflow, statistics.rs:275-287) */
+#define ESIM_ETIMEDOUT  -7   /* sharded run: no progress within the deadline (a peer left or died); the RCCL communicator was aborted */
 
 /* DiseaseStatus codes, sim/src/disease.rs:36-44 */
 enum { ESIM_SUSCEPTIBLE = 0, ESIM_EXPOSED = 1, ESIM_INFECTED = 2, ESIM_RECOVERED = 3, ESIM_VACCINATED = 4 };
@@ -176,15 +177,29 @@ int  esim_exchange_buffer(esim_ctx *ctx, int which /* 0 = A, 1 = B, 2 = F */, vo
  *                            an ncclAllReduce enqueued on the context's stream between its kernels
  * esim_comm_init_callback -- instead: the caller's own SUM all-reduce over the ranks, in place, of `n_u32` uint32 in HOST memory
  *                            at `host_ptr` (the library stages the device buffer through it with the stream drained; `which`
- *                            names the buffer: 0 A, 1 B, 2 F, 3 plan liveness, 4 commuter records, 5 cuts, 6 records);
+ *                            names the buffer: 0 A, 1 B, 2 F, 3 plan liveness, 4 commuter records, 5 cuts, 6 records, 7 status,
+ *                            8 the set-up's layout check);
  *                            returns 0 on success.  For transports other than RCCL and for tests with several ranks on one GPU.
  * esim_run_sharded        -- replaces the loop of Simulator::simulate (simulator.rs:114-123) for this rank's shard: n_steps
  *                            time steps, every rank calling it with the same n_steps; records of these steps hold the census
  *                            of the WHOLE population on every rank. */
+/* Set-up.  esim_comm_init_* come AFTER esim_upload_population (a new upload invalidates the communicator) and are collective:
+ * the ranks' shards are checked against each other with one small all-reduce -- rank r must hold the r-th stretch of the global
+ * citizen ids of ONE world (same n_citizens_global, shared tables of the same size), else ESIM_EINVAL on every rank that sees
+ * the mismatch.  world <= 31.
+ * Failure semantics (the reference bubbles a failed step() up to main, run/src/main.rs:306-308): the shards' device-side error
+ * words are summed in the same collectives that carry the data, and before every read-back of the control block, so ALL ranks
+ * return from esim_run_sharded together and with the same ESIM_E* code (records of that call are then undefined); the host's
+ * waits on a stream that holds RCCL collectives have a deadline (esim_comm_set_timeout, default 60 s, or ESIM_COMM_TIMEOUT_S):
+ * on expiry the communicator is aborted (ncclCommAbort) and the call returns ESIM_ETIMEDOUT -- exit with an error then.
+ * esim_run_sharded has no early stop (a shard cannot know that the disease is gone elsewhere): it always runs n_steps.
+ * esim_debug_inject_error: diagnostics -- raises a sticky device-side error on this context (tests of the above). */
 typedef int (*esim_allreduce_fn)(void *user, int which, void *host_ptr, size_t n_u32);
 int  esim_comm_unique_id(void *out, size_t cap);
 int  esim_comm_init_rccl(esim_ctx *ctx, const void *unique_id, size_t id_bytes, int rank, int world);
 int  esim_comm_init_callback(esim_ctx *ctx, esim_allreduce_fn fn, void *user, int rank, int world);
+int  esim_comm_set_timeout(esim_ctx *ctx, double seconds);
+int  esim_debug_inject_error(esim_ctx *ctx, int code);
 int  esim_comm_stats(esim_ctx *ctx, uint64_t *collectives);
 int  esim_run_sharded(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_done);
 /* How the steps of sharded runs were executed so far: as time-parallel chunks (one round of exchanges per chunk) / as coupled

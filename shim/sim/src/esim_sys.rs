@@ -109,6 +109,9 @@ extern "C" {
     pub fn esim_comm_unique_id(out: *mut c_void, cap: usize) -> c_int;
     pub fn esim_comm_init_rccl(ctx: *mut c_void, unique_id: *const c_void, id_bytes: usize, rank: c_int, world: c_int) -> c_int;
     pub fn esim_comm_init_callback(ctx: *mut c_void, f: EsimAllreduceFn, user: *mut c_void, rank: c_int, world: c_int) -> c_int;
+    // (set-up comes after esim_upload_population and checks the ranks' shards against each other; every rank returns from
+    // esim_run_sharded together and with the same code; ESIM_ETIMEDOUT (-7) when a peer left -- exit with an error then)
+    pub fn esim_comm_set_timeout(ctx: *mut c_void, seconds: f64) -> c_int;
     pub fn esim_run_sharded(ctx: *mut c_void, n_steps: u32, n_done: *mut u32) -> c_int;
     pub fn esim_last_error(ctx: *const c_void) -> *const c_char;
     pub fn esim_destroy(ctx: *mut c_void);

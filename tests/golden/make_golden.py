@@ -62,6 +62,13 @@ def reference_envelope():
     out["areas_with_exposures"] = int(per_area.size)
     out["exposures_share_top25_areas"] = float(per_area[:25].sum() / per_area.sum())
     out["final_record"] = {k: int(stats[-1][k]) for k in ("time_step", "susceptible", "exposed", "infected", "recovered", "vaccinated")}
+    # Q10 (simulator.rs:481-553): the record of the step whose end created citizens_eligible_for_vaccine -- its Susceptible count
+    # IS the size of the set -- and the Vaccinated census every 250 steps from there on: with `rate` ids chosen per step and never
+    # removed, E[V after k batches] = E * (1 - (1 - rate / E)^k), which the test checks on the reference's own curve
+    trig = int(np.argmax(vac > 0)) - 1                     # the last record without a Vaccinated citizen: the trigger step
+    out["vaccination_trigger_record"] = {k: int(stats[trig][k]) for k in ("time_step", "susceptible", "exposed", "infected", "recovered", "vaccinated")}
+    out["vaccination_rate_observed"] = int(vac[trig + 1])
+    out["vaccinated_series"] = {str(int(stats[i]["time_step"])): int(vac[i]) for i in range(trig + 1, len(stats)) if (i - trig) % 250 == 0 or i == len(stats) - 1}
     with open(os.path.join(HERE, "reference_york_v171_envelope.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(out)

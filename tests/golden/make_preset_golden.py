@@ -1,7 +1,7 @@
 """Golden records of the benchmark workloads at full size: the CPU oracle on a synthetic preset for 5000 steps (uk64m: more
 than an hour and 6 GB).  Writes tests/golden/oracle_<preset>_5000.json: every record of the first 100 steps, every 50th
-record after that with the exposure totals of its block, and sha256 digests of the full per-citizen state after steps
-100 and 5000 (tests/_oracle.py: state_digest).
+record after that with the exposure totals of its block, and sha256 digests of the full per-citizen state after step
+100 and after every 1000th step (tests/_oracle.py: state_digest).
   python tests/golden/make_preset_golden.py [preset] [oracle threads]"""
 import json, os, sys, time
 import numpy as np
@@ -31,7 +31,7 @@ while done < 5000:
     rows.append({k: int(r[k][-1]) for k in FIELDS})
     rows[-1]["exposures_building_block"] = int(r["exposures_building"].sum())
     rows[-1]["exposures_bus_block"] = int(r["exposures_bus"].sum())
-    if done in (100, 5000):
+    if done == 100 or done % 1000 == 0:
         digests[str(done)] = _oracle.state_digest(orc.state())
     if done % 250 == 0:
         print(done, rows[-1], "%.0f s" % (time.time() - t0), flush=True)

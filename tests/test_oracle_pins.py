@@ -239,6 +239,15 @@ def test_oracle_meets_the_reference_recorded_york_run():
     # a seed drawn in an area without citizens is lost (simulator_builder.rs:1125-1136), so 10 is the maximum
     assert all(8 <= r["seed_infected_first_record"] <= env["seed_infected_first_record"] for r in runs)
     assert sum(r["recovered_decreases"] for r in runs) >= 6
+    # Q10, pinned to the reference's own file: its Vaccinated census follows E (1 - (1 - 85/E)^k) -- "85 distinct members of a
+    # set that never shrinks" -- at all 16 sampled records (the final 160 868 against an expected 160 815); every run of the
+    # ensemble satisfies the same identity with its own E and trigger step, and the same end-of-run bookkeeping
+    assert env["vaccination_trigger_record"]["time_step"] == env["first_vaccinated_record"] - 1 == 1028
+    assert _envelope.q10_identity(env, 85) < 1.0                # the reference's curve sits within one sigma everywhere
+    for r in runs:
+        assert _envelope.q10_identity(r, 85) <= 3.0, r["k"]
+        n = r["final_record"]
+        assert n["susceptible"] + n["exposed"] + n["infected"] + n["recovered"] + n["vaccinated"] == env["n_citizens"]
     # and the spread itself must stay informative: the median run within a factor 1.5 of the reference
     for key in ("peak_infected", "exposures_total"):
         med = float(np.median([r[key] for r in runs]))

@@ -109,7 +109,8 @@ def test_york_default_params_1000_steps():
 
 def test_york_full_5000_steps_vaccination_85():
     # BASELINE.json configs[1]: York, 5000 steps, fixed Philox seed vs CPU counts; v1.7.1's rate 85/step
-    run_both(Population.synthetic("york"), 5000, small_limits=("tp", "pipe", None), vaccination_rate=85, vaccination_threshold=0.003)
+    # (forms: planned chunks under the programme -- the default, level 3 --, chunks until it starts, one kernel per step, sequential)
+    run_both(Population.synthetic("york"), 5000, small_limits=("vax", "tp", "pipe", None), vaccination_rate=85, vaccination_threshold=0.003)
 
 
 def test_yh_census_config_1500_steps():
@@ -242,6 +243,18 @@ def test_checkpoint_resume_continues_bit_for_bit(tmp_path):
     with pytest.raises(_lib.EsimError, match="another population"):
         other.load_checkpoint(path)
     other.close(); whole.close()
+    # a checkpoint written by a build that lays the state out differently (its header carries a hash of the citizen word's
+    # fields and of the control block's layout: CkptHeader.layout_id, the 16th u32 of the file) is refused, not reinterpreted
+    raw = np.fromfile(path, np.uint8)
+    raw[15 * 4] ^= 0x5A
+    bad = str(tmp_path / "other_layout.bin")
+    raw.tofile(bad)
+    c = Simulator(pop, ep)
+    with pytest.raises(_lib.EsimError, match="another state layout"):
+        c.load_checkpoint(bad)
+    c.load_checkpoint(path)                                   # the context is still usable, and the genuine file still goes in
+    assert_same_records(np.concatenate([first, c.run(500 - at)]), ref)
+    c.close()
 
 
 def test_simulate_after_a_resume_finishes_the_same_run(tmp_path, capsys):

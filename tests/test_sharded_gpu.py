@@ -104,6 +104,42 @@ def test_few_eligible_candidates_need_more_than_one_batch():
     assert all("ok" in o for o in outs)
 
 
+def test_a_rank_whose_chunks_never_fit_takes_every_rank_to_coupled_steps():
+    # ESIM_HASH_LOG2=4 on rank 1 only: its chunks can never take the one-pass form, rank 0's can.  The "cannot" word of buffer F
+    # is summed, so both ranks skip the chunk together and back off to coupled steps -- same records as the oracle
+    cfg = dict(backend="gloo", cuts="even", spec=dict(n_citizens=12000, n_areas=40, citizens_per_school=2500, n_seeds=16),
+               params=AGGRESSIVE, steps=240, chunk=120, env_by_rank={"1": {"ESIM_HASH_LOG2": 4}}, pipeline=3, expect_coupled=200)
+    outs = launch(2, cfg)
+    assert all("ok" in o for o in outs)
+
+
+def test_commuter_segment_grows_with_the_need():
+    # the all-gathered segment of Infected commuters starts at 2 records per rank here (ESIM_XS_CAP): every chunk that needs
+    # more is a no-op on all ranks, the segment doubles (the need is gathered too, so all ranks agree) and the chunk runs again
+    cfg = dict(backend="gloo", cuts="even", spec=dict(n_citizens=12000, n_areas=40, citizens_per_school=2500, n_seeds=16),
+               params=AGGRESSIVE, steps=360, chunk=120, expect=dict(vaccinated=1),
+               env_by_rank={"0": {"ESIM_XS_CAP": 2}, "1": {"ESIM_XS_CAP": 2}})
+    outs = launch(2, cfg)
+    assert all("ok" in o for o in outs)
+
+
+def test_one_ranks_device_error_makes_every_rank_return_it():
+    # failure semantics of a sharded run (the reference bubbles a failed step up to main, run/src/main.rs:306-308): no rank is
+    # left inside a collective when another one fails -- in the chunk form and in the coupled-step form
+    for pipeline in (3, 0):
+        cfg = dict(backend="gloo", mode="inject", bad_rank=1, pipeline=pipeline, steps=120, pg_timeout=60,
+                   spec=dict(n_citizens=12000, n_areas=40, citizens_per_school=2500, n_seeds=16), params=AGGRESSIVE)
+        outs = launch(2, cfg, timeout=180)
+        assert all("raised ERANGE" in o for o in outs), outs
+
+
+def test_shards_that_do_not_belong_together_are_refused():
+    cfg = dict(backend="gloo", mode="mismatch", pg_timeout=60,
+               spec=dict(n_citizens=12000, n_areas=40, citizens_per_school=2500, n_seeds=16), params=AGGRESSIVE)
+    outs = launch(2, cfg, timeout=180)
+    assert all("refused" in o for o in outs), outs
+
+
 def test_syn3m5_two_shards_match_oracle():
     # BASELINE.json configs[3]: synthetic 3.5 M citizens, Output-Area sharded with even cuts (here 2 ranks on the test GPU):
     # commuters to schools across the cut, every step coupled

@@ -89,3 +89,64 @@ def test_shared_slot_exchange_world_size_2():
         errs.append(errq.get())
     assert not errs, "\n".join(errs)
     assert all(p.exitcode == 0 for p in procs)
+
+
+def _uid_worker(rank, world, port, errq):
+    """The RCCL unique id cannot be made on rank 0 (as when librccl does not load there): every rank must raise, promptly and
+    in step -- none may be left inside the broadcast (the old code raised on rank 0 BEFORE the broadcast)."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import datetime
+        import torch.distributed as dist
+        from epidemicsimulator_amd import _lib
+        from epidemicsimulator_amd.distributed import exchange_unique_id
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+
+        class FakeLib:                                   # rccl().ok == false on rank 0
+            def esim_comm_unique_id(self, buf, cap):
+                return -2 if rank == 0 else 0
+            def esim_last_error(self, ctx):
+                return b"librccl could not be loaded"
+
+        try:
+            exchange_unique_id(FakeLib(), dist, rank)
+            raise AssertionError("rank %d: no error although rank 0 could not make the id" % rank)
+        except _lib.EsimError as ex:
+            assert ex.code == -2 and "librccl" in str(ex)
+        # the ranks are still in step: the next collective matches
+        import torch
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        assert int(t.item()) == world * (world + 1) // 2
+
+        class GoodLib(FakeLib):
+            def esim_comm_unique_id(self, buf, cap):
+                for i in range(128):
+                    buf[i] = (i * 7 + 1) & 0xFF
+                return 0
+        raw = exchange_unique_id(GoodLib(), dist, rank)
+        assert raw == bytes(((i * 7 + 1) & 0xFF) for i in range(128))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        errq.put("rank %d: %s\n%s" % (rank, e, traceback.format_exc()))
+        raise
+
+
+def test_unique_id_failure_on_rank_0_reaches_every_rank_world_size_2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    errq = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uid_worker, args=(r, 2, port, errq)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    errs = []
+    while not errq.empty():
+        errs.append(errq.get())
+    assert not errs, "\n".join(errs)
+    assert all(p.exitcode == 0 for p in procs)
