@@ -500,6 +500,10 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         HIP_TRY(c, hipMemset(d.xc, 0, sizeof(uint32_t) * (FREE_MAX + 2u)));
         d.rank = 0; d.world = 1; d.xs = nullptr;
     }
+#ifdef ESIM_COUNT_WORK
+    if ((rc = dev_alloc(c, &d.work_cnt, (size_t)WK_N))) return rc;
+    HIP_TRY(c, hipMemset(d.work_cnt, 0, sizeof(unsigned long long) * WK_N));
+#endif
 #ifdef ESIM_WAVE_PROFILE
     if ((rc = dev_alloc(c, &d.prof_buf, (size_t)16384 * 16))) return rc;
     HIP_TRY(c, hipMemset(d.prof_buf, 0, sizeof(uint32_t) * 16384 * 16));
@@ -1496,6 +1500,22 @@ extern "C" int esim_debug_counters(esim_ctx *ctx, uint32_t out[16])
     std::memcpy(out, v, sizeof v);
     return ESIM_OK;
 }
+
+#ifdef ESIM_COUNT_WORK
+// counting build only (not in include/esim.h): what the chunk pass worked on since the last call (WK_* in esim_kernels_common.h)
+extern "C" int esim_work_counters(esim_ctx *ctx, unsigned long long *out, uint32_t n)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !c->uploaded || !out) return ESIM_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long h[WK_N];
+    HIP_TRY(c, hipMemcpy(h, c->d.work_cnt, sizeof h, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemset(c->d.work_cnt, 0, sizeof h));
+    for (uint32_t i = 0; i < n; ++i) out[i] = i < WK_N ? h[i] : 0ull;
+    return ESIM_OK;
+}
+#endif
 
 #ifdef ESIM_WAVE_PROFILE
 // diagnostics build only (not in include/esim.h): rows of per-wavefront timers, and the timer's rate in kHz

@@ -233,6 +233,9 @@ struct Dev {
     uint32_t *xc;                       // [FREE_MAX + 2] steps of the chunk with a cut (k_chunk_count)
     uint32_t *xe;                       // [2] status exchange: [0] error fields (ERR_FIELD), [1] shards that are finished
     const int32_t *shared_of_bld, *shared_of_room;   // [n_bld], [n_room]: index into the shared tables, -1 when not shared
+#ifdef ESIM_COUNT_WORK
+    unsigned long long *work_cnt;       // counting build only: [WK_N] what the chunk pass worked on (tools/work_counts.py)
+#endif
 #ifdef ESIM_WAVE_PROFILE
     uint32_t *prof_buf;                 // diagnostics build only: [wavefronts][16] timers of the last chunk (tools/wave_profile.py)
 #endif

@@ -599,6 +599,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
     const M96 BUS = { __ballot(lane < n && q0.bus_dir != 0u), (uint32_t)__ballot(64u + lane < n && q1.bus_dir != 0u) };
     const unsigned long long lt = (1ull << lane) - 1ull;
     const uint32_t pm0 = PROF_NOW();
+    WORK_TALLY;
     uint32_t p_entries = 0u;
     uint32_t my_pairs = 0u;                                                   // (route, bus step) pairs this wavefront registered
     uint32_t ps[5] = { 0u, 0u, 0u, 0u, 0u };                                   // diagnostics: time per stage
@@ -657,7 +658,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         // (a commuter from another shard only counts where it works: its home and its route are its own shard's business)
         const bool any_home = !remote && m96_any(ath), any_work = m96_any(atw), any_bus = !remote && m96_any(onbus);
         const bool school = w & FL_WORK_SCHOOL;
-        if (any_home || any_work || any_bus) ++p_entries;
+        if (any_home || any_work || any_bus) { ++p_entries; WORK_ADD(WK_ENTRIES, 1); }
         // the four keys: home building, work building, room, route
         uint32_t src[4] = { 0u, r_bld, r_room, 0u };
         if (any_home) src[0] = d.home[c];
@@ -689,6 +690,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         for (uint32_t k = 0; k < 4u; ++k) {
             claimed[k] = false; pending[k] = false;
             if (key[k] == HKEY_EMPTY) continue;
+            WORK_ADD(WK_KEYS, 1);
             if (seen[k] == HKEY_EMPTY) claimed[k] = true;
             else if (seen[k] == key[k]) pending[k] = true;
             else {
@@ -719,6 +721,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) {
             if (claimed[k]) {
+                WORK_ADD(WK_CLAIMS, 1);
                 const uint32_t v = next_id + before++;
                 d.hitems[v] = slot[k];
                 const uint32_t id = (uint32_t)key[k];
@@ -766,6 +769,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         for (uint32_t k = 0; k < 3u; ++k) {
             direct[k] = k == 1u && school && key[1] != HKEY_EMPTY; first[k] = false;
             if (!add_rec[k]) continue;
+            WORK_ADD(WK_RECORDS, 1);
             const uint32_t iv = k == 0u ? iv_home : iv_work;
             if (old[k] < ITEM_RECS) { d.slot_iv[(size_t)slot[k] * SLOT_IV_STRIDE + old[k]] = iv; continue; }
             const uint32_t q = old[k] - ITEM_RECS, id = (uint32_t)key[k];
@@ -802,6 +806,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
                 const uint32_t sl = __shfl(slot[k], src_lane, 64), hi = __shfl(at.hi, src_lane, 64);
                 const unsigned long long lo = ((unsigned long long)__shfl((uint32_t)(at.lo >> 32), src_lane, 64) << 32) | __shfl((uint32_t)at.lo, src_lane, 64);
                 uint32_t *v = d.vec + (size_t)sl * FREE_MAX;
+                WORK_ADD(WK_DIRECT, ((lo >> lane) & 1ull) + ((lane < 32u && ((hi >> lane) & 1u)) ? 1 : 0));
                 if ((lo >> lane) & 1ull) atomicAdd(&v[lane], 1u);
                 if (lane < 32u && ((hi >> lane) & 1u)) atomicAdd(&v[64u + lane], 1u);
             }
@@ -842,6 +847,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         { const uint32_t pf = PROF_NOW(); ps[0] += pb - pa; ps[1] += pc - pb; ps[2] += pd - pc; ps[3] += pe - pd; ps[4] += pf - pe; }
     }
     if (lane == 0) { d.pair_cnt[wave] = my_pairs; d.used_cnt[wave] = next_id - wave * per_wave; }
+    WORK_FLUSH(d);
     const uint32_t pm1 = PROF_NOW();
     PROF_PUT(d, 8, pm0); PROF_PUT(d, 9, pm1); PROF_PUT(d, 10, p_entries);
     PROF_PUT(d, 11, ps[0]); PROF_PUT(d, 12, ps[1]); PROF_PUT(d, 13, ps[2]); PROF_PUT(d, 14, ps[3]); PROF_PUT(d, 15, ps[4]);
@@ -896,6 +902,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
     PROF_PUT(d, 11, 0u); PROF_PUT(d, 12, 0u); PROF_PUT(d, 13, 0u);
 #endif
     if (first >= n_list) return;
+    WORK_TALLY;
     const uint32_t *bl = d.big_list + (size_t)qr * d.big_qcap * 3u;
     const Decision q0 = lane < n ? d.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
     const Decision q1 = 64u + lane < n ? d.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
@@ -927,6 +934,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
             const uint32_t slot = FX(slot_l, i), base = FX(base_l, i), n_ov = FX(n_ov_l, i);
             uint32_t iv = ivs[u];
             uint32_t c0 = 0u, c1 = 0u;
+            WORK_ADD(WK_FOLDED, lane == 0 ? n_ov : 0);
 #ifdef ESIM_PROFILE_FOLD
             pq_rec += n_ov; ++pq_n;
 #endif
@@ -955,6 +963,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
         }
         }
     }
+    WORK_FLUSH(d);
 #ifdef ESIM_PROFILE_FOLD
     PROF_PUT(d, 11, pq_n); PROF_PUT(d, 12, PROF_NOW() - pq0); PROF_PUT(d, 13, pq_rec);
 #endif
@@ -996,7 +1005,7 @@ struct WaveScratch { uint32_t rounds; uint32_t cnt[FREE_MAX]; uint32_t sch[FREE_
 // kind 0 residents, 1 workers, 2 room participants.
 // pre_m / pre_w: members lo + pre_base + lane of the list and their words when the caller has already fetched them (have_pre).
 __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, WaveScratch &ws, const uint32_t *idx,
-                                             uint32_t lo, uint32_t p_lo, uint32_t p_hi, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0,
+                                             uint32_t lo, uint32_t p_lo, uint32_t p_hi, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0 WORK_ARG,
                                              bool have_pre = false, uint32_t pre_m = 0u, uint32_t pre_w = 0u, uint32_t pre_base = 0u)
 {
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
@@ -1005,6 +1014,7 @@ __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const Chu
     for (uint32_t mb = m_first; mb <= m_last; mb += 64u) {
         __builtin_amdgcn_wave_barrier();
         if (mb + lane <= m_last) {
+            WORK_ADD(WK_MEMBERS, 1); WORK_ADD(WK_MEMBERS_IDX, idx ? 1 : 0);
             if (have_pre && mb == pre_base) { ws.mem_id[lane] = pre_m; ws.mem_w[lane] = pre_w; }
             else {
                 const uint32_t m = idx ? idx[lo + mb + lane] : lo + mb + lane;
@@ -1021,6 +1031,7 @@ __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const Chu
             const uint32_t um = p / S, si = p - um * S;
             const uint32_t m = ws.mem_id[um - mb], w = ws.mem_w[um - mb];
             const uint32_t te = CW_TE(w);
+            WORK_ADD(WK_PAIRS, 1);
             if (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) continue;
             const uint4 dsc = ws.desc[2u * si];
             const uint32_t cnt23 = ws.desc[2u * si + 1u].x;
@@ -1038,6 +1049,7 @@ __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const Chu
             const uint32_t here = kind == 0u ? (((w & FL_HAS_WORK) && !same) ? ~atw : 15u) : (same ? 15u : atw);
             const uint32_t act = mk & early & here;
             if (!act) continue;
+            WORK_ADD(WK_PAIRS_ACTIVE, 1);
             const uint32_t nn = kind == 2u ? dsc.z : dsc.y;                    // exposure_count & 255 per step: infected in the building
             const uint32_t row = (w & FL_MASK_COMPLIANT) ? 0u : everywhere;   // steps in which this member's chance is the masked one
             uint64_t thr[SLOT_STEPS];
@@ -1053,20 +1065,25 @@ __device__ __forceinline__ void member_pairs(const Dev &d, Ctrl *ctrl, const Chu
 #pragma unroll
                 for (uint32_t h = 0; h < SLOT_STEPS; ++h) if ((act >> h) & 1u) kmax = max(kmax, cnt[h]);
                 const uint32_t first_act = act & (0u - act);
+#ifdef ESIM_COUNT_WORK
+                for (uint32_t h = 0; h < SLOT_STEPS; ++h) if ((act >> h) & 1u) WORK_ADD(WK_DRAWS, cnt[h]);
+#endif
                 for (uint32_t k = 0; k < kmax && !(hit & first_act); ++k) {
+                    WORK_ADD(WK_BLOCKS, 1);
                     const philox_out o = esim_draw_block(seed, gid, s_blk, ESIM_SLOT_ROOM0 + k);
                     const uint32_t wd[SLOT_STEPS] = { o.w0, o.w1, o.w2, o.w3 };
 #pragma unroll
                     for (uint32_t h = 0; h < SLOT_STEPS; ++h) if (((act >> h) & 1u) && k < cnt[h] && (uint64_t)wd[h] < thr[h]) hit |= 1u << h;
                 }
             } else {
+                WORK_ADD(WK_BLOCKS, 1); WORK_ADD(WK_DRAWS, __popc(act));
                 const philox_out o = esim_draw_block(seed, gid, s_blk, kind == 0u ? ESIM_SLOT_HOME : ESIM_SLOT_WORK);
                 const uint32_t wd[SLOT_STEPS] = { o.w0, o.w1, o.w2, o.w3 };
 #pragma unroll
                 for (uint32_t h = 0; h < SLOT_STEPS; ++h) if ((uint64_t)wd[h] < thr[h]) hit |= 1u << h;
                 hit &= act;
             }
-            if (hit) expose_min(d, ctrl, m, w, (uint32_t)((int)t0 + jb) + (uint32_t)__builtin_ctz(hit), 0u);   // (the earliest wins anyway)
+            if (hit) { WORK_ADD(WK_HITS, 1); expose_min(d, ctrl, m, w, (uint32_t)((int)t0 + jb) + (uint32_t)__builtin_ctz(hit), 0u); }   // (the earliest wins anyway)
         }
     }
 }
@@ -1140,12 +1157,12 @@ __device__ __forceinline__ void school_counts(const Dev &d, uint32_t s_sch, uint
 // where in it the unit's first pair falls.
 struct UnitSrc { uint32_t slot, link, own; };
 __device__ __forceinline__ void list_or_units(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, WaveScratch &ws, const uint32_t *idx,
-                                              uint32_t lo, uint32_t hi, const UnitSrc &src, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0,
+                                              uint32_t lo, uint32_t hi, const UnitSrc &src, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0 WORK_ARG,
                                               bool have_pre = false, uint32_t pre_m = 0u, uint32_t pre_w = 0u)
 {
     const uint32_t pairs = (hi - lo) * S;
     if (pairs == 0) return;
-    if (pairs <= UNIT_PAIRS) { member_pairs(d, ctrl, sm, ws, idx, lo, 0u, pairs, lane, kind, S, t0, have_pre, pre_m, pre_w); return; }
+    if (pairs <= UNIT_PAIRS) { member_pairs(d, ctrl, sm, ws, idx, lo, 0u, pairs, lane, kind, S, t0 WORK_PASS, have_pre, pre_m, pre_w); return; }
     const uint32_t n_units = (pairs + UNIT_PAIRS - 1u) / UNIT_PAIRS;
     const uint32_t r = ((blockIdx.x * TPB + threadIdx.x) >> 6) & (SUBQ - 1u);  // this wavefront's queue
     uint32_t start = 0;
@@ -1155,7 +1172,7 @@ __device__ __forceinline__ void list_or_units(const Dev &d, Ctrl *ctrl, const Ch
     if (start + n_units > d.unit_qcap) {
         // queue full: what was reserved of it becomes no-ops and the list is drawn here
         for (uint32_t i = lane; i < n_units && start + i < d.unit_qcap; i += 64u) q[start + i].code = UNIT_NOOP;
-        member_pairs(d, ctrl, sm, ws, idx, lo, 0u, pairs, lane, kind, S, t0, have_pre, pre_m, pre_w);
+        member_pairs(d, ctrl, sm, ws, idx, lo, 0u, pairs, lane, kind, S, t0 WORK_PASS, have_pre, pre_m, pre_w);
         return;
     }
     for (uint32_t i = lane; i < n_units; i += 64u) {
@@ -1248,6 +1265,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;   // <= CHUNK_WAVES_MAX (esim_create)
     const uint32_t pt0 = PROF_NOW();
+    WORK_TALLY;
     uint32_t p_items = 0u, p_item_max = 0u;
     // The wavefronts of k_chunk_marks (same grid) each handed out the first used_cnt[w] ids of [w * per_wave, ...): whoever
     // reaches a key first claims its item, so the early wavefronts hold far more items than the late ones.  The pass
@@ -1318,7 +1336,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
         if (it.id >= route_base) continue;
         const uint32_t pi0 = PROF_NOW();
         pst[0] += pi0 - pq0;
-        (void)pi0; ++p_items;
+        (void)pi0; ++p_items; WORK_ADD(WK_ITEMS, lane == 0 ? 1 : 0);
         if (it.id < d.n_bld) {
             if (it.aux == ESIM_SCHOOL) continue;                              // School::find_exposures works per room
             // first 64 residents and workers and their words: both lists' loads are in flight together
@@ -1334,9 +1352,9 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
             const uint32_t pq2 = PROF_NOW();
             // Household / Workplace::find_exposures: every registered occupant (building.rs:202-204,278-280)
             const UnitSrc src = { it.slot, it.link, FX(x, 7) };
-            list_or_units(d, ctrl, sm, ws, d.res_idx, it.a_lo, it.a_hi, src, lane, 0u, S, t0, true, rm, rw);
+            list_or_units(d, ctrl, sm, ws, d.res_idx, it.a_lo, it.a_hi, src, lane, 0u, S, t0 WORK_PASS, true, rm, rw);
             const uint32_t pq3 = PROF_NOW();
-            list_or_units(d, ctrl, sm, ws, d.wrk_idx, it.b_lo, it.b_hi, src, lane, 1u, S, t0, true, wm, ww);
+            list_or_units(d, ctrl, sm, ws, d.wrk_idx, it.b_lo, it.b_hi, src, lane, 1u, S, t0 WORK_PASS, true, wm, ww);
             const uint32_t pq4 = PROF_NOW();
             pst[1] += pq1 - pi0; pst[2] += pq2 - pq1; pst[3] += pq3 - pq2; pst[4] += pq4 - pq3;
         } else {
@@ -1349,7 +1367,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
             __builtin_amdgcn_wave_barrier();
             // School::find_exposures: the room once per infected in it (building.rs:494-522)
             const UnitSrc src = { it.slot, it.link, FX(x, 7) };
-            list_or_units(d, ctrl, sm, ws, d.room_idx, it.a_lo, it.a_hi, src, lane, 2u, S, t0, true, mm, mw);
+            list_or_units(d, ctrl, sm, ws, d.room_idx, it.a_lo, it.a_hi, src, lane, 2u, S, t0 WORK_PASS, true, mm, mw);
         }
         __builtin_amdgcn_wave_barrier();
         { const uint32_t dt = PROF_NOW() - pi0; p_item_max = dt > p_item_max ? dt : p_item_max; }
@@ -1381,6 +1399,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
         const uint32_t s = t0 + j, mask = sm.dec[j].mask;
         uint32_t c = 0, w = 0, key = 0;
         bool inf = false;
+        WORK_ADD(WK_ROUTE_PAIRS, lane == 0 ? 1 : 0); WORK_ADD(WK_RIDERS, lane < sz ? 1 : 0);
         if (lane < sz) {
             c = d.route_riders[off + lane];
             w = d.cit[c];
@@ -1405,11 +1424,13 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
             const uint32_t te = CW_TE(w);
             if (!(w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_KEEP)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) || j > CW_VAX_REL(w))) {   // not exposed before this bus, not Vaccinated by then
                 const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
-                if (esim_u32(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
+                WORK_ADD(WK_BUS_DRAWS, 1);
+                if (esim_u32(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) { WORK_ADD(WK_HITS, 1); expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED); }
             }
         }
         }
     }
+    WORK_FLUSH(d);
     const uint32_t pt3 = PROF_NOW();
 #ifndef ESIM_PROFILE_UNITS
     PROF_PUT(d, 0, pt0); PROF_PUT(d, 1, pt1); PROF_PUT(d, 2, pt2); PROF_PUT(d, 3, pt3);   // start, after preamble, after items, end
@@ -1433,6 +1454,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
     const uint32_t pu0 = PROF_NOW();
+    WORK_TALLY;
     uint32_t pu_n = 0u, pu_max = 0u, pu_it = 0u;
     // queue `wave & 63`, every (n_waves / 64)-th unit of it
     const uint32_t qr = wave & (SUBQ - 1u), first = wave / SUBQ, step = n_waves / SUBQ;
@@ -1491,11 +1513,13 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
         const uint32_t S = item_steps_regs(c0, c1, lane, ws, t0, AW, EV);
         __builtin_amdgcn_wave_barrier();
         const uint32_t pairs = n_mem * S;
-        member_pairs(d, ctrl, sm, ws, idx, lo, p_lo, min(pairs, p_lo + UNIT_PAIRS), lane, kind, S, t0, true, mid, mw, mf);
+        WORK_ADD(WK_UNITS, lane == 0 ? 1 : 0);
+        member_pairs(d, ctrl, sm, ws, idx, lo, p_lo, min(pairs, p_lo + UNIT_PAIRS), lane, kind, S, t0 WORK_PASS, true, mid, mw, mf);
         __builtin_amdgcn_wave_barrier();
         { const uint32_t dt = PROF_NOW() - pui; pu_max = dt > pu_max ? dt : pu_max; pu_it += (min(pairs, p_lo + UNIT_PAIRS) - p_lo + 63u) / 64u; }
     }
     const uint32_t pu2 = PROF_NOW();
+    WORK_FLUSH(d);
 #ifdef ESIM_PROFILE_UNITS
     PROF_PUT(d, 0, pu0); PROF_PUT(d, 1, pu1); PROF_PUT(d, 2, pu2); PROF_PUT(d, 4, pu_n); PROF_PUT(d, 5, pu_max); PROF_PUT(d, 7, pu_it);
 #endif
@@ -1506,8 +1530,10 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
         if (r >= d.n_routes || j >= n) { if (threadIdx.x == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); continue; }   // (block-uniform)
         const uint32_t off = d.route_off[r], sz = d.route_off[r + 1] - off;
         const uint32_t s = t0 + j, mask = sm.dec[j].mask;
+        WORK_ADD(WK_ROUTE_PAIRS, threadIdx.x == 0 ? 1 : 0);
         for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
             const uint32_t c = d.route_riders[off + i];
+            WORK_ADD(WK_RIDERS, 1);
             rs.s_key[i] = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
             rs.s_inf[i] = status_in_chunk(d, d.cit[c], t0, j) == ESIM_INFECTED ? 1 : 0;
         }
@@ -1529,10 +1555,12 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
             const uint32_t w = d.cit[c], te = CW_TE(w);
             if (w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_KEEP)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) || j > CW_VAX_REL(w)) continue;   // exposed before this bus, or Vaccinated by then
             const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
-            if (esim_u32(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED);
+            WORK_ADD(WK_BUS_DRAWS, 1);
+            if (esim_u32(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) { WORK_ADD(WK_HITS, 1); expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED); }
         }
         __syncthreads();
     }
+    WORK_FLUSH(d);
 }
 
 // Exposures per step (statistics.rs:181) from the final citizen words -- the many-workgroup form, for chunks with many new

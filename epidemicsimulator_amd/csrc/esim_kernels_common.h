@@ -106,3 +106,41 @@ __device__ __forceinline__ void append(uint32_t *list, uint32_t *len, uint32_t v
 #define PROF_PUT(d, i, v) do { (void)sizeof(v); } while (0)
 #endif
 
+
+// Counting build (make count; tools/work_counts.py): what the chunk pass WORKS ON, counted exactly -- the sparse pass's own
+// units of work, which its roofline is priced in.  Per-lane tallies are summed over the wavefront where all its
+// lanes meet again and added to 64-bit device counters by lane 0; nothing of this exists in the product build.
+#ifdef ESIM_COUNT_WORK
+enum { WK_ENTRIES = 0,      // Infected log entries (and received commuter records) k_chunk_marks looked at
+       WK_KEYS,             // hash keys looked up / claimed (home, work, room, route per entry)
+       WK_CLAIMS,           // items claimed
+       WK_RECORDS,          // interval records left with somebody else's item (slot records + overflow)
+       WK_DIRECT,           // per-step counter atomics (schools, commuters of other shards)
+       WK_FOLDED,           // overflow records k_chunk_fold summed
+       WK_ITEMS,            // items k_chunk_draw took (buildings, rooms)
+       WK_MEMBERS,          // member entries staged for drawing (id + citizen word each)
+       WK_MEMBERS_IDX,      // ... of which through an index list (workers, room participants): 4 more bytes each
+       WK_PAIRS,            // (member, slot of four time steps) pairs looked at
+       WK_PAIRS_ACTIVE,     // ... that take at least one draw
+       WK_BLOCKS,           // Philox4x32-10 blocks computed for exposure draws
+       WK_DRAWS,            // Bernoulli draws the reference would make: (member, step) pairs, one per Infected room-mate in rooms
+       WK_UNITS,            // deferred units drawn by k_chunk_units
+       WK_ROUTE_PAIRS,      // (route, bus step) pairs ranked
+       WK_RIDERS,           // riders ranked (one Philox block each for the order key) 
+       WK_BUS_DRAWS,        // bus draws (one Philox block each)
+       WK_HITS,             // successful draws (atomicMin issued)
+       WK_N };
+#define WORK_TALLY uint32_t wk_[WK_N]; for (int wk_i = 0; wk_i < WK_N; ++wk_i) wk_[wk_i] = 0u
+#define WORK_ADD(i, x) (wk_[i] += (uint32_t)(x))
+// (all lanes of the wavefront must be here together)
+#define WORK_FLUSH(d) do { for (int wk_i = 0; wk_i < WK_N; ++wk_i) { uint32_t x_ = wk_[wk_i]; for (int o_ = 32; o_ > 0; o_ >>= 1) x_ += __shfl_xor(x_, o_, 64); \
+        if ((threadIdx.x & 63u) == 0 && x_) atomicAdd(&(d).work_cnt[wk_i], (unsigned long long)x_); wk_[wk_i] = 0u; } } while (0)
+#define WORK_ARG , uint32_t *wk_
+#define WORK_PASS , wk_
+#else
+#define WORK_TALLY do { } while (0)
+#define WORK_ADD(i, x) do { } while (0)
+#define WORK_FLUSH(d) do { } while (0)
+#define WORK_ARG
+#define WORK_PASS
+#endif

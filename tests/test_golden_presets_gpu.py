@@ -2,7 +2,7 @@
 (tests/golden/make_preset_golden.py: the oracle needs seconds to more than an hour for these, the GPU milliseconds to seconds).
 Compared: every record of the first 100 steps, every 50th record after that with the exposure totals of its block of 50,
 and the sha256 digest of the FULL per-citizen state (status, timer, position, bus, eligibility of every citizen) after
-steps 100 and 5000.  The run is driven as bench.py drives it: esim_run over the speculative bursts of time-parallel chunks."""
+step 100 and after every 1000th step.  The run is driven as bench.py drives it: esim_run over the speculative bursts of time-parallel chunks."""
 import json
 import os
 import sys
@@ -34,7 +34,13 @@ def test_full_length_run_matches_offline_oracle(preset):
         for f in CENSUS + ("exposures_building", "exposures_bus"):
             assert int(rec[i][f]) == want[f], (preset, f, want["time_step"], int(rec[i][f]), want[f])
     assert _oracle.state_digest(sim.download_state()) == gold["state_sha256"]["100"], "per-citizen state after step 100"
-    rec = np.concatenate([rec, sim.run(gold["steps"] - 100)])
+    # ... and after every step the golden holds a digest for (every 1000th), the run continuing from there
+    done = 100
+    for at in sorted(int(k) for k in gold["state_sha256"] if int(k) > 100):
+        rec = np.concatenate([rec, sim.run(at - done)])
+        done = at
+        assert _oracle.state_digest(sim.download_state()) == gold["state_sha256"][str(at)], "per-citizen state after step %d" % at
+    assert done == gold["steps"]
     every = gold["every"]
     for i, want in enumerate(gold["records"]):
         got = rec[(i + 1) * every - 1]
@@ -43,5 +49,4 @@ def test_full_length_run_matches_offline_oracle(preset):
         block = rec[i * every:(i + 1) * every]
         assert int(block["exposures_building"].sum()) == want["exposures_building_block"], (preset, want["time_step"])
         assert int(block["exposures_bus"].sum()) == want["exposures_bus_block"], (preset, want["time_step"])
-    assert _oracle.state_digest(sim.download_state()) == gold["state_sha256"][str(gold["steps"])], "per-citizen state at the end"
     sim.close()

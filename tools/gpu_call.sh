@@ -1,0 +1,14 @@
+#!/bin/bash
+# One GPU-box call of this round: steps joined so that a failing GPU step ends the call (no GPU step after a fault).
+# usage: bash tools/gpu_call.sh tag step...   steps: tests calib prof bench
+tag=$1; shift
+mkdir -p gpurun_out
+for step in "$@"; do
+  case $step in
+    tests) timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_$tag.log 2>&1; rc=$?; tail -5 gpurun_out/pytest_$tag.log; [ $rc -eq 0 ] || exit $rc ;;
+    calib) timeout -k 10 300 bash tools/calib_passes.sh > gpurun_out/calib_$tag.log 2>&1; rc=$?; tail -12 gpurun_out/calib_$tag.log; [ $rc -eq 0 ] || exit $rc ;;
+    prof) timeout -k 10 900 bash tools/profile_passes_r03.sh $tag uk64m > gpurun_out/prof_$tag.log 2>&1; rc=$?; tail -70 gpurun_out/prof_$tag.log; cp profiles/${tag}_* gpurun_out/ 2>/dev/null; [ $rc -eq 0 ] || exit $rc ;;
+    bench) timeout -k 10 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err; rc=$?; cut -c1-1500 gpurun_out/bench_$tag.json; [ $rc -eq 0 ] || { tail -5 gpurun_out/bench_$tag.err; exit $rc; } ;;
+    *) echo "unknown step $step"; exit 9 ;;
+  esac
+done
