@@ -64,6 +64,14 @@ struct esim_ctx_impl {
     uint32_t *xr = nullptr; size_t xr_n = 0;      // records exchange (sharded chunks)
     uint64_t shard_chunk_steps = 0, shard_step_steps = 0;
     uint64_t comm_calls = 0;
+    // pinned host mirrors: the control block and the records of the call in flight come back with ONE stream wait (two blocking
+    // copies into pageable memory cost more than a small chunk's kernels)
+    Ctrl *pin_ctrl = nullptr;
+    esim_step_result *pin_rec = nullptr; size_t pin_rec_n = 0;
+    uint32_t pin_first = 0, pin_valid = 0;        // records [pin_first, pin_first + pin_valid) of the call in flight are in pin_rec
+    bool pin_track = false;
+    bool ctrl_fresh = false;                      // pin_ctrl holds the control block as it stands (nothing was enqueued since)
+    uint32_t stop_flag_dev = 0;                   // what ctrl->stop_when_done holds (written only when it changes)
     double comm_timeout_s = 60.0;      // deadline of a host wait on a stream that holds collectives (esim_comm_set_timeout)
     std::vector<hipEvent_t> fev; size_t fev_used = 0;                               // chunks of an open decoupled burst
     std::vector<hipEvent_t> pkev; size_t pkev_used = 0; uint64_t pipe_steps = 0;   // sampled k_pipe launches
@@ -218,6 +226,8 @@ extern "C" void esim_destroy(esim_ctx *ctx)
     for (auto &ev : c->pkev) (void)hipEventDestroy(ev);
     for (auto &ev : c->fev) (void)hipEventDestroy(ev);
     for (auto &ev : c->cev) if (ev) (void)hipEventDestroy(ev);
+    if (c->pin_ctrl) (void)hipHostFree(c->pin_ctrl);
+    if (c->pin_rec) (void)hipHostFree(c->pin_rec);
     if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -349,6 +359,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     d.n = N; d.n_global = n_global; d.id_base = pop->citizen_id_base; d.n_bld = B; d.n_room = R;
     d.n_pt = (uint32_t)riders.size(); d.n_routes = n_routes; c->n_routes = n_routes;
     d.max_route = max_route;
+    d.draw_dynamic = std::getenv("ESIM_DRAW_STATIC") ? 0u : 1u;
     int rc;
     if ((rc = dev_alloc(c, &d.cit, (size_t)N + 1))) return rc;
     if ((rc = dev_upload(c, &d.home, pop->home_building, N))) return rc;
@@ -519,6 +530,13 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     HIP_TRY(c, hipMemset(d.xa, 0, sizeof(uint32_t) * c->xa_n));
     HIP_TRY(c, hipMemset(d.xb, 0, sizeof(uint32_t) * c->xb_n));
 
+    if (!c->pin_ctrl) HIP_TRY(c, hipHostMalloc((void **)&c->pin_ctrl, sizeof(Ctrl), hipHostMallocDefault));
+    if (c->pin_rec_n < (size_t)c->P.max_steps + 1) {
+        if (c->pin_rec) (void)hipHostFree(c->pin_rec);
+        c->pin_rec = nullptr; c->pin_rec_n = 0;
+        HIP_TRY(c, hipHostMalloc((void **)&c->pin_rec, sizeof(esim_step_result) * ((size_t)c->P.max_steps + 1), hipHostMallocDefault));
+        c->pin_rec_n = (size_t)c->P.max_steps + 1;
+    }
     c->grid_citizens = grid_for(N, TPB, 2048);
     c->grid_infected = 1024;
     c->grid_expose = 1024;
@@ -558,6 +576,8 @@ extern "C" int esim_reset(esim_ctx *ctx)
     HIP_TRY(c, hipMemcpy(d.log_off, off.data(), sizeof(uint32_t) * (TE_SLOTS + 1), hipMemcpyHostToDevice));
     if (n_seeds) HIP_TRY(c, hipMemcpy(d.log, c->init_log.data(), sizeof(uint32_t) * n_seeds, hipMemcpyHostToDevice));
     c->host_t = 1;
+    c->stop_flag_dev = 0;
+    c->pin_track = false;
     c->free_limit = 0;
     c->last_chunk_pairs = (uint32_t)c->init_log.size();
     c->phase_s[0] = c->phase_s[1] = c->phase_s[2] = 0;
@@ -636,6 +656,30 @@ bool want_kernel_timing(esim_ctx_impl *c)
 int fail_dev(esim_ctx_impl *c, uint32_t err)
 {
     return fail(c, -(int)err, "device-side error (S underflow / vaccination window exhausted / a chunk table overflowed)");
+}
+
+// The control block through the pinned mirror: an asynchronous copy and one wait.
+int read_ctrl(esim_ctx_impl *c, Ctrl *h)
+{
+    HIP_TRY(c, hipMemcpyAsync(c->pin_ctrl, c->d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *h = *c->pin_ctrl;
+    return ESIM_OK;
+}
+
+// After a burst of chunk passes that started at step `first` and can have advanced `span` steps at most: the control block and
+// the records of those steps come back with one wait (esim_run hands the records on from the mirror).
+int burst_readback(esim_ctx_impl *c, uint32_t first, uint32_t span, Ctrl *h)
+{
+    const Dev &d = c->d;
+    HIP_TRY(c, hipMemcpyAsync(c->pin_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+    const bool rec = c->pin_track && first == c->pin_first + c->pin_valid && (size_t)first + span <= c->pin_rec_n;
+    if (rec) HIP_TRY(c, hipMemcpyAsync(c->pin_rec + first, d.records + first, sizeof(esim_step_result) * span, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *h = *c->pin_ctrl;
+    if (rec && h->t >= first) c->pin_valid += std::min<uint32_t>(h->t - first, span);
+    c->ctrl_fresh = true;
+    return ESIM_OK;
 }
 
 int device_error(esim_ctx_impl *c)
@@ -817,6 +861,7 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
     if (c->elig_seen && (!vax_ok || n_steps < 8u)) sequential_only = true;
     uint32_t vax_fail = 0;
     while (remaining > 0) {
+        c->ctrl_fresh = false;
         if (sequential_only) {
             uint32_t done = 0;
             if ((rc = run_sequential(c, remaining, allow_early_stop, &done))) return rc;
@@ -833,8 +878,7 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             for (uint32_t g = 0; g < bursts; ++g) enqueue_vax_chunk(c, limit_t);
             if (tk) HIP_TRY(c, hipEventRecord(c->cev[1], c->stream));
             Ctrl h;
-            HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if ((rc = burst_readback(c, first, std::min<uint32_t>(remaining, bursts * (uint32_t)c->xf_n), &h))) return rc;
             HIP_TRY(c, hipGetLastError());
             if (h.error) return fail(c, -(int)h.error, "device-side error");
             const uint32_t done = h.t - first;
@@ -869,8 +913,7 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             for (uint32_t g = 0; g < bursts; ++g) enqueue_parallel_chunk(c, g + 1u < bursts ? 1 : 0, limit_t);
             if (tk) HIP_TRY(c, hipEventRecord(c->cev[1], c->stream));
             Ctrl h;
-            HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if ((rc = burst_readback(c, first, std::min<uint32_t>(remaining, bursts * (uint32_t)c->xf_n), &h))) return rc;
             HIP_TRY(c, hipGetLastError());
             if (h.error) return fail(c, -(int)h.error, "device-side error");
             const uint32_t done = h.t - first;
@@ -947,16 +990,31 @@ extern "C" int esim_run(esim_ctx *ctx, uint32_t n_steps, int stop_when_done, esi
     HIP_TRY(c, hipSetDevice(c->P.device));
     const uint32_t first = c->host_t;
     const uint32_t flag = stop_when_done ? 1u : 0u;
-    HIP_TRY(c, hipMemcpyAsync(&c->d.ctrl->stop_when_done, &flag, sizeof flag, hipMemcpyHostToDevice, c->stream));
-    if ((rc = run_steps(c, n_steps, stop_when_done != 0, nullptr))) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (flag != c->stop_flag_dev) {                      // (the flag lives in the control block; written only when it changes)
+        HIP_TRY(c, hipMemcpyAsync(&c->d.ctrl->stop_when_done, &flag, sizeof flag, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->stop_flag_dev = flag;
+    }
+    // bursts of chunk passes bring their records back together with the control block (burst_readback); whatever other forms
+    // ran is fetched below
+    c->pin_track = out_array != nullptr; c->pin_first = first; c->pin_valid = 0; c->ctrl_fresh = false;
+    rc = run_steps(c, n_steps, stop_when_done != 0, nullptr);
+    c->pin_track = false;
+    if (rc) return rc;
     Ctrl h;
-    HIP_TRY(c, hipMemcpy(&h, c->d.ctrl, sizeof h, hipMemcpyDeviceToHost));
+    if (c->ctrl_fresh) h = *c->pin_ctrl;
+    else if ((rc = read_ctrl(c, &h))) return rc;
     if (h.error) return fail(c, -(int)h.error, "device-side error (S underflow / vaccination window exhausted)");
     const uint32_t done = h.steps_done >= first ? h.steps_done - first + 1 : 0;
     c->host_t = first + done;
-    if (out_array && done)
-        HIP_TRY(c, hipMemcpy(out_array, &c->d.records[first], sizeof(esim_step_result) * done, hipMemcpyDeviceToHost));
+    if (out_array && done) {
+        const uint32_t have = std::min(c->pin_valid, done);
+        if (have < done) {
+            HIP_TRY(c, hipMemcpyAsync(c->pin_rec + first + have, c->d.records + first + have, sizeof(esim_step_result) * (done - have), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        std::memcpy(out_array, c->pin_rec + first, sizeof(esim_step_result) * done);
+    }
     if (n_done) *n_done = done;
     return ESIM_OK;
 }

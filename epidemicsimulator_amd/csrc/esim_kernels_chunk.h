@@ -1247,12 +1247,6 @@ __device__ __forceinline__ bool item_ok(const Dev &d, const ItemFetch &it)
     if (it.id < d.n_bld + d.n_room) return it.a_lo <= it.a_hi && it.a_hi <= d.n_room_idx && (it.link == 0xFFFFFFFFu || it.link < d.hcap);
     return true;
 }
-__device__ __forceinline__ bool unit_ok(const Dev &d, uint32_t kind, uint32_t slot, uint32_t link, uint32_t lo, uint32_t n_mem)
-{
-    const uint32_t len = kind == 2u ? d.n_room_idx : kind == 1u ? d.n_wrk_idx : d.n;
-    return kind <= 2u && slot < d.hcap && (link == 0xFFFFFFFFu || link < d.hcap) && lo <= len && n_mem <= len - lo;
-}
-
 #define PAIR_SPREAD 1237u
 // apply_exposures (simulator.rs:262-405) for every item and every step of the chunk.
 __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
@@ -1273,16 +1267,30 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     // (k_chunk_fold left the prefix sums of used_cnt in used_pref).
     const uint32_t per_wave = ld(&ctrl->items_per_wave);
     if ((unsigned long long)per_wave * n_waves > d.items_cap) return;          // (k_chunk_marks raised ESIM_ERANGE and left no items)
-    // this wavefront's stretch [d_lo, d_hi) of the T items, and the wavefront of k_chunk_marks that owns d_lo: the last one
-    // whose ids start at or before it -- first among every 64th, then among the 64 from there on
+    // Equal stretches are equal in ITEMS, not in work: a few hundred items per wavefront with member lists of 2 to 200 leave
+    // the slowest of 4096 wavefronts ~35 % behind the mean (r02: 2.8 of 4 wavefronts resident per SIMD over the launch).  So
+    // only the first DRAW_STATIC_16THS / 16 of the items are dealt as fixed stretches; the rest is DRAW_POOLS pools of blocks of
+    // DRAW_BLOCK items that the wavefronts take as they finish (one returning atomic per block, a counter per pool: a single
+    // word saturates at ~88 dequeues / us, MI355X_MICROARCH.md "dequeue"; a wavefront starts with pool `wave % DRAW_POOLS`).
+    // Chunks of few items keep the fixed stretches alone: their time is latency, not balance.
     const uint32_t T = d.used_pref[n_waves];
     const uint32_t coarse = d.used_pref[min(64u * lane, n_waves)];
-    const uint32_t Tq = T / n_waves, Tr = T % n_waves;                         // (T * wave / n_waves without 64-bit division)
-    const uint32_t d_lo = Tq * wave + Tr * wave / n_waves, d_hi = Tq * (wave + 1u) + Tr * (wave + 1u) / n_waves;
-    // lane l: where the ids of owner ow_base + l start in the dense sequence (a window of 64 owners, moved on when used up)
-    uint32_t ow_base = 64u * ((uint32_t)__popcll(__ballot(64u * lane < n_waves && coarse <= d_lo)) - 1u);
-    uint32_t win = d.used_pref[min(ow_base + lane, n_waves)];
-    uint32_t ow = ow_base + (uint32_t)__popcll(__ballot(ow_base + lane < n_waves && win <= d_lo)) - 1u;
+    const bool dynamic = d.draw_dynamic && T >= DRAW_DYNAMIC_MIN * n_waves;
+    const uint32_t T_static = dynamic ? (uint32_t)(((unsigned long long)T * DRAW_STATIC_16THS) >> 4) : T;
+    const uint32_t Tq = T_static / n_waves, Tr = T_static % n_waves;           // (T_static * wave / n_waves without 64-bit division)
+    uint32_t d_lo = Tq * wave + Tr * wave / n_waves, d_hi = Tq * (wave + 1u) + Tr * (wave + 1u) / n_waves;
+    const uint32_t pool_sz = (T - T_static + DRAW_POOLS - 1u) / DRAW_POOLS;     // items per pool (the last one may be shorter)
+    uint32_t pool = wave % DRAW_POOLS, pools_tried = 0u;
+    // the wavefront of k_chunk_marks that owns dense index i: the last one whose ids start at or before it -- first among
+    // every 64th (`coarse`, kept for the whole kernel), then among the 64 from there on (`win`: lane l holds where the ids of owner
+    // ow_base + l start; a window of 64 owners, moved on when used up)
+    uint32_t ow_base = 0u, win = 0u, ow = 0u;
+    auto seek = [&](uint32_t i) {
+        ow_base = 64u * ((uint32_t)__popcll(__ballot(64u * lane < n_waves && coarse <= i)) - 1u);
+        win = d.used_pref[min(ow_base + lane, n_waves)];
+        ow = ow_base + (uint32_t)__popcll(__ballot(ow_base + lane < n_waves && win <= i)) - 1u;
+    };
+    seek(d_lo);
     // item id of dense index i; called with ascending i
     auto id_of = [&](uint32_t i) -> uint32_t {
         for (;;) {
@@ -1323,7 +1331,8 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
 #endif
     uint32_t pst[5] = { 0u, 0u, 0u, 0u, 0u };
     const uint32_t pt1 = PROF_NOW();
-    // (1) buildings and school rooms: one wavefront per item
+    // (1) buildings and school rooms: one wavefront per item; the fixed stretch first, then blocks from the pools
+    for (;;) {
     for (uint32_t v = d_lo; v < d_hi; ++v) {
         const uint32_t x = merge_fetch(id_cur, sl_cur, lane);
         id_cur = id_nxt;
@@ -1371,6 +1380,24 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
         }
         __builtin_amdgcn_wave_barrier();
         { const uint32_t dt = PROF_NOW() - pi0; p_item_max = dt > p_item_max ? dt : p_item_max; }
+    }
+    // the next block: from this wavefront's pool while it lasts, then from the others in turn
+    if (!dynamic) break;
+    bool got = false;
+    while (pools_tried < DRAW_POOLS) {
+        const uint32_t p_lo = T_static + pool * pool_sz, p_hi = min(T, p_lo + pool_sz);
+        uint32_t blk = 0u;
+        if (lane == 0) blk = p_lo < p_hi ? atomicAdd(&d.hot[(HOT_DRAWQ + pool) * HOT_STRIDE], 1u) : 0xFFFFFFu;
+        blk = FX(blk, 0);
+        const unsigned long long lo64 = (unsigned long long)p_lo + (unsigned long long)blk * DRAW_BLOCK;
+        if (lo64 < p_hi) { d_lo = (uint32_t)lo64; d_hi = min(p_hi, d_lo + DRAW_BLOCK); got = true; break; }
+        pool = pool + 1u == DRAW_POOLS ? 0u : pool + 1u; ++pools_tried;      // this pool is used up (for good: its counter only grows)
+    }
+    if (!got) break;
+    seek(d_lo);
+    id_cur = fetch_item(d, id_of(d_lo), lane);
+    if (d_lo + 1u < d_hi) id_nxt = fetch_item(d, id_of(d_lo + 1u), lane);
+    sl_cur = fetch_slot(d, FX(id_cur, LANE_HSLOT), lane);
     }
     const uint32_t pt2 = PROF_NOW();
     // (2) routes of <= 64 riders: one wavefront per (route, bus step) with an Infected rider; rank by (Philox key, id)
@@ -1474,10 +1501,12 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
     // Per unit: its record (lanes 0..7 of one register); then, together, the slot's interval records, the school's, and the
     // ids of the first members its pairs touch; then those members' words.  The record of the unit after next and the
     // second stage of the next are in flight while this one draws.
+    // (unit records are written by k_chunk_draw from items it has checked (item_ok), into queues that are initialised to
+    // no-ops; what a record names as hash slots is checked by fetch_slot, which fetches nothing for a value that is no slot)
     auto unit_words = [&](uint32_t q) -> uint32_t { return lane < 8u ? q_words[(size_t)q * 8u + lane] : 0u; };
     auto member_id = [&](uint32_t u) -> uint32_t {
         const uint32_t code = FX(u, 4), kind = code >> 30, lo = FX(u, 2), n_mem = FX(u, 3), mf = FX(u, 6);
-        if (code == UNIT_NOOP || mf + lane >= n_mem || !unit_ok(d, kind, FX(u, 0), FX(u, 1), lo, n_mem)) return 0u;
+        if (code == UNIT_NOOP || mf + lane >= n_mem) return 0u;
         const uint32_t *idx = kind == 2u ? d.room_idx : kind == 1u ? d.wrk_idx : d.res_idx;
         return idx ? idx[lo + mf + lane] : lo + mf + lane;
     };
@@ -1498,7 +1527,6 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
         const uint32_t pui = PROF_NOW();
         ++pu_n;
         const uint32_t kind = code >> 30, p_lo = code & 0x3FFFFFFFu, slot = FX(u, 0), link = FX(u, 1), lo = FX(u, 2), n_mem = FX(u, 3), own = FX(u, 5), mf = FX(u, 6);
-        if (!unit_ok(d, kind, slot, link, lo, n_mem)) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); continue; }
         const uint32_t mw = (mf + lane < n_mem) ? d.cit[mid] : 0u;
         uint32_t c0, c1;
         item_counts(d, xs, slot, lane, n, AW, BUS, c0, c1);

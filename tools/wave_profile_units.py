@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, '.')
-os.environ.setdefault("ESIM_LIB", os.path.abspath("epidemicsimulator_amd/libesim_prof.so"))
+os.environ.setdefault("ESIM_LIB", os.path.abspath("epidemicsimulator_amd/libesim_profu.so"))
 from epidemicsimulator_amd import Population, Simulator, _lib
 pop = Population.synthetic(sys.argv[1] if len(sys.argv) > 1 else "uk64m")
 sim = Simulator(pop, _lib.default_params(max_steps=5000))
