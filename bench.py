@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 MODEL_BYTES_PER_CITIZEN_STEP = 26.0     # state R+W 4, flags 2, home/work/room ids 12, two count gathers 8
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+N_SIMD = 1024.0                         # 256 CUs x 4 SIMDs
 CENSUS = ("susceptible", "exposed", "infected", "recovered", "vaccinated")
 # the arithmetic the path computes in -- not a precision claim (RNG contract)
 DTYPE = "u32 citizen word; u32 uniform vs ceil(q*2^32) (reference: f64 uniform; tolerance 2^-32 per draw)"
@@ -265,27 +266,53 @@ def main():
             full["golden_check"] = golden_check(args.preset, rec5, int(params.seed))
             full["value"] = pop.n_citizens * 5000 / (full["wall_us_per_step"] * 5000 * 1e-6)
         out["full_run"] = dict(full, workload="%s, all 5000 steps" % args.preset)
-    # ---- roofline of the dominant work: the time-parallel chunk pass.  HBM bytes per time step come from the PMC passes of the same
-    # workload kept under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md); device time per step is measured here.
+    # ---- roofline of the dominant kernel of the chunk pass.  Its average launch duration is measured HERE: one more full run
+    # with a HIP event in front of every chunk kernel on the context's stream (esim_chunk_kernel_timings).  What a launch moves
+    # and issues comes from the rocprofv3 passes of the same command kept under profiles/ (current_<preset>.json, written by
+    # profiles/summarize_r03.py): HBM-side bytes request-size exact (TCC_EA0_RDREQ_32B/_64B/_128B, WRREQ/_64B: on gfx950 every
+    # read request is 128 B, whatever the access width -- profiles/*_tcc_calibration.md), SQ_ACTIVE_INST_VALU, SQ_WAVE_CYCLES,
+    # and the counting build's tallies (draws, Philox blocks, useful bytes).  The pass is sparse: it never touches most of
+    # SURVEY 8(d)'s 26 B x citizens (kept as `model_bytes` for context), so it is priced against the two roofs it can hit --
+    # HBM lines and vector issue -- and `bound` names the nearer one.
     rf = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
     ppath = os.path.join(ROOT, "profiles", "current_%s.json" % args.preset)
-    if os.path.exists(ppath):
+    if os.path.exists(ppath) and not args.no_extra_runs:
         prof = json.load(open(ppath))
-        bytes_per_step = prof["hbm_bytes_per_step"]
-        dev_us = full["device_us_per_step"]
-        achieved = bytes_per_step / (dev_us * 1e-6) / 1e9 if dev_us > 0 else 0.0
-        model = MODEL_BYTES_PER_CITIZEN_STEP * pop.n_citizens
-        dom = max(prof["kernels"].items(), key=lambda kv: kv[1]["total_ms"])
-        rf.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": bytes_per_step,
-                   "launch": "one time step of the full 5000-step run (a chunk pass covers up to 96 of them)",
-                   "avg_launch_ms": dev_us * 1e-3, "counters_from": os.path.relpath(ppath, ROOT) + " <- " + prof["tag"],
-                   "model_bytes": model, "traffic_over_model": bytes_per_step / model,
-                   "dominant_kernel": {"name": dom[0], "share_of_device_time": dom[1]["pct"] / 100.0, "avg_us": dom[1]["avg_us"],
-                                       "hbm_bytes_per_launch": dom[1]["hbm_bytes_per_launch"], "achieved_GBs": dom[1]["achieved_GBs"],
-                                       "frac": dom[1]["frac_of_peak"]},
-                   "note": "the pass visits Infected citizens and the members of the buildings they stand in, not all citizens: its HBM traffic is a "
-                           "small fraction of the model's 26 B x citizens per step, and what bounds it is memory latency, Philox arithmetic and "
-                           "kernel boundaries (DESIGN.md 5)"})
+        sim.enable_chunk_kernel_timing(True)
+        _, kinfo = timed_run(sim, 5000)
+        kt = sim.chunk_kernel_timings()
+        sim.enable_chunk_kernel_timing(False)
+        dev_ms = sum(v["ms"] for v in kt.values())
+        dom = max(kt, key=lambda k: kt[k]["ms"])
+        pk = prof["kernels"].get("k_chunk_" + dom) or prof["kernels"].get("k_" + dom)
+        if pk and kt[dom]["calls"]:
+            dur_s = kt[dom]["ms"] * 1e-3 / kt[dom]["calls"]                      # live average launch duration
+            hbm_bytes = pk["hbm_bytes_exact"] / pk["calls"]
+            valu_cyc = pk["SQ_ACTIVE_INST_VALU"] * 4.0 / pk["calls"]             # SIMD-cycles with a VALU instruction active, per launch
+            wave_cyc = pk["SQ_WAVE_CYCLES"] * 4.0 / pk["calls"]
+            hbm = {"achieved_GBs": hbm_bytes / dur_s / 1e9, "peak_GBs": HBM_PEAK_GBS, "frac": hbm_bytes / dur_s / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": hbm_bytes,
+                   "read_requests_32B_64B_128B_per_launch": [x / pk["calls"] for x in pk["read_requests_32B_64B_128B"]]}
+            valu = {"busy_simd_cycles_per_launch": valu_cyc, "frac_at_2.4GHz": valu_cyc / (N_SIMD * 2.4e9 * dur_s), "frac_at_2.1GHz": valu_cyc / (N_SIMD * 2.1e9 * dur_s),
+                    "resident_wavefronts_per_simd_at_2.4GHz": wave_cyc / (N_SIMD * 2.4e9 * dur_s), "launched_wavefronts_per_simd": 4.0,
+                    "note": "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x clock x launch duration); the chip holds 2.1-2.4 GHz under this load"}
+            near_valu = valu["frac_at_2.4GHz"] >= hbm["frac"]
+            rf = {"bound": "valu" if near_valu else "hbm",
+                  "achieved": valu_cyc / dur_s / 1e9 if near_valu else hbm["achieved_GBs"], "peak": N_SIMD * 2.4 if near_valu else HBM_PEAK_GBS,
+                  "unit": "G SIMD-cycles/s with a vector instruction active (peak: 1024 SIMDs x 2.4 GHz)" if near_valu else "GB/s",
+                  "frac": valu["frac_at_2.4GHz"] if near_valu else hbm["frac"], "traffic": hbm_bytes,
+                  "kernel": "k_chunk_" + dom, "share_of_chunk_pass_device_time": kt[dom]["ms"] / dev_ms, "launches": kt[dom]["calls"], "avg_launch_ms": dur_s * 1e3,
+                  "avg_launch_ms_in_the_profile": pk["avg_us"] * 1e-3, "hbm": hbm, "valu": valu,
+                  "counters_from": os.path.relpath(ppath, ROOT) + " <- " + prof["tag"],
+                  "model_bytes": MODEL_BYTES_PER_CITIZEN_STEP * pop.n_citizens, "model_note": "SURVEY 8(d): 26 B x citizens per time step -- what a DENSE pass would move; "
+                  "the sparse pass moves %.4f of it per step" % (prof["hbm_bytes_exact_per_step"] / (MODEL_BYTES_PER_CITIZEN_STEP * pop.n_citizens)),
+                  "device_ms_per_kernel": {k: round(v["ms"], 3) for k, v in kt.items() if v["calls"]}}
+            w = prof.get("work")
+            if w:
+                run_s = dev_ms * 1e-3
+                rf.update({"draws_per_s": w["counts"]["draws"] / run_s, "philox_blocks_per_s": w["counts"]["philox_blocks"] / run_s,
+                           "member_slot_pairs_per_s": w["counts"]["pairs"] / run_s, "useful_bytes_per_run": w["useful_bytes"],
+                           "useful_over_fetched": w["useful_bytes"] / (prof["hbm_bytes_exact_per_step"] * prof["steps"]),
+                           "useful_bytes_model": w["useful_bytes_model"]})
     out["roofline"] = rf
     if not args.no_extra_runs and args.preset != "york":
         # a run that spends most of its steps under a vaccination programme: BASELINE.json configs[1]

@@ -72,6 +72,10 @@ struct esim_ctx_impl {
     bool pin_track = false;
     bool ctrl_fresh = false;                      // pin_ctrl holds the control block as it stands (nothing was enqueued since)
     uint32_t stop_flag_dev = 0;                   // what ctrl->stop_when_done holds (written only when it changes)
+    // per-kernel device time of the chunk pass (esim_enable_chunk_kernel_timing): an event in front of every kernel of a chunk
+    bool kdetail = false;
+    std::vector<hipEvent_t> kdev; std::vector<int> kd_kind; size_t kd_used = 0;
+    double kd_ms[ESIM_CK_N] = { 0 }; uint64_t kd_calls[ESIM_CK_N] = { 0 };
     double comm_timeout_s = 60.0;      // deadline of a host wait on a stream that holds collectives (esim_comm_set_timeout)
     std::vector<hipEvent_t> fev; size_t fev_used = 0;                               // chunks of an open decoupled burst
     std::vector<hipEvent_t> pkev; size_t pkev_used = 0; uint64_t pipe_steps = 0;   // sampled k_pipe launches
@@ -226,6 +230,7 @@ extern "C" void esim_destroy(esim_ctx *ctx)
     for (auto &ev : c->pkev) (void)hipEventDestroy(ev);
     for (auto &ev : c->fev) (void)hipEventDestroy(ev);
     for (auto &ev : c->cev) if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->kdev) (void)hipEventDestroy(ev);
     if (c->pin_ctrl) (void)hipHostFree(c->pin_ctrl);
     if (c->pin_rec) (void)hipHostFree(c->pin_rec);
     if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -667,6 +672,8 @@ int read_ctrl(esim_ctx_impl *c, Ctrl *h)
     return ESIM_OK;
 }
 
+void kd_resolve(esim_ctx_impl *c);
+
 // After a burst of chunk passes that started at step `first` and can have advanced `span` steps at most: the control block and
 // the records of those steps come back with one wait (esim_run hands the records on from the mirror).
 int burst_readback(esim_ctx_impl *c, uint32_t first, uint32_t span, Ctrl *h)
@@ -679,6 +686,7 @@ int burst_readback(esim_ctx_impl *c, uint32_t first, uint32_t span, Ctrl *h)
     *h = *c->pin_ctrl;
     if (rec && h->t >= first) c->pin_valid += std::min<uint32_t>(h->t - first, span);
     c->ctrl_fresh = true;
+    if (c->kdetail) kd_resolve(c);
     return ESIM_OK;
 }
 
@@ -764,6 +772,26 @@ int run_sequential(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, ui
     return ESIM_OK;
 }
 
+// Per-kernel timing of the chunk pass: an event in front of every kernel (kind = which one), ESIM_CK_N closes a sequence.
+// kd_resolve turns consecutive events into durations once the stream has drained.
+void kd_mark(esim_ctx_impl *c, int kind)
+{
+    if (!c->kdetail) return;
+    if (c->kd_used == c->kdev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c->kdev.push_back(e); c->kd_kind.push_back(0); }
+    if (hipEventRecord(c->kdev[c->kd_used], c->stream) != hipSuccess) return;
+    c->kd_kind[c->kd_used++] = kind;
+}
+
+void kd_resolve(esim_ctx_impl *c)
+{
+    for (size_t i = 0; i + 1 < c->kd_used; ++i) {
+        if (c->kd_kind[i] >= ESIM_CK_N) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->kdev[i], c->kdev[i + 1]) == hipSuccess) { c->kd_ms[c->kd_kind[i]] += ms; c->kd_calls[c->kd_kind[i]]++; }
+    }
+    c->kd_used = 0;
+}
+
 // The kernels of one time-parallel chunk; they take the chunk (first step, length, whether it may run this way)
 // from the control block as k_decide left it, and do nothing when it may not.
 // then_next: also prepare the chunk after it (census ahead + decisions: what k_future and k_decide do), for steps up to limit_t.
@@ -774,13 +802,19 @@ void enqueue_parallel_chunk(esim_ctx_impl *c, int then_next, uint32_t limit_t)
 {
     Dev &d = c->d;
     const bool small = c->last_chunk_pairs < 1024u;
+    kd_mark(c, ESIM_CK_MARKS);
     hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    kd_mark(c, ESIM_CK_FOLD);
     hipLaunchKernelGGL(k_chunk_fold, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    kd_mark(c, ESIM_CK_DRAW);
     hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    kd_mark(c, ESIM_CK_UNITS);
     hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
-    if (!small) hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
+    if (!small) { kd_mark(c, ESIM_CK_COUNT); hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d); }
+    kd_mark(c, ESIM_CK_BOOKS);
     hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, small ? 1 : 0, then_next, (uint32_t)c->xf_n, limit_t);
-    if (!small) hipLaunchKernelGGL(k_chunk_scatter, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);   // (same grid as k_chunk_count: their workgroups pair up)
+    if (!small) { kd_mark(c, ESIM_CK_SCATTER); hipLaunchKernelGGL(k_chunk_scatter, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d); }   // (same grid as k_chunk_count: their workgroups pair up)
+    kd_mark(c, ESIM_CK_N);
 }
 
 // One time-parallel chunk under a vaccination programme: census ahead, the plan of the chunk's vaccinations and what it does
@@ -789,17 +823,29 @@ void enqueue_parallel_chunk(esim_ctx_impl *c, int then_next, uint32_t limit_t)
 void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
 {
     Dev &d = c->d;
+    kd_mark(c, ESIM_CK_VAX);
     hipLaunchKernelGGL(k_chunk_vax, dim3(FREE_MAX + 1u), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 0);   // (+ the census ahead)
+    kd_mark(c, ESIM_CK_VAX_ADJ);
     hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+    kd_mark(c, ESIM_CK_DECIDE);
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 0);
+    kd_mark(c, ESIM_CK_MARKS);
     hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    kd_mark(c, ESIM_CK_FOLD);
     hipLaunchKernelGGL(k_chunk_fold, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    kd_mark(c, ESIM_CK_DRAW);
     hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    kd_mark(c, ESIM_CK_UNITS);
     hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    kd_mark(c, ESIM_CK_COUNT);
     hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
+    kd_mark(c, ESIM_CK_BOOKS);
     hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, 0, 0, (uint32_t)c->xf_n, limit_t);
+    kd_mark(c, ESIM_CK_SCATTER);
     hipLaunchKernelGGL(k_chunk_scatter, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);   // (same grid as k_chunk_count: their workgroups pair up)
+    kd_mark(c, ESIM_CK_VAX_FINAL);
     hipLaunchKernelGGL(k_chunk_vax_final, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d);
+    kd_mark(c, ESIM_CK_N);
 }
 
 // One pipelined chunk.  Precondition: k_future ran for the current step (and, when sharded, buffer F was
@@ -908,7 +954,9 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             const uint32_t bursts = std::min<uint32_t>((remaining + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n, probing ? 1u : 16u);   // (the form of a chunk's book-keeping is chosen from what the last read-back showed)
             const bool tk = c->kernel_timing;
             if (tk) { if (!c->cev[0]) { (void)hipEventCreate(&c->cev[0]); (void)hipEventCreate(&c->cev[1]); } HIP_TRY(c, hipEventRecord(c->cev[0], c->stream)); }
+            kd_mark(c, ESIM_CK_FUTURE);
             hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+            kd_mark(c, ESIM_CK_DECIDE);
             hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 0);
             for (uint32_t g = 0; g < bursts; ++g) enqueue_parallel_chunk(c, g + 1u < bursts ? 1 : 0, limit_t);
             if (tk) HIP_TRY(c, hipEventRecord(c->cev[1], c->stream));
@@ -1526,6 +1574,29 @@ extern "C" int esim_chunk_timing(esim_ctx *ctx, double *total_ms, uint64_t *step
     if (steps) *steps = c->chunk_steps;
     if (chunks) *chunks = c->chunk_count;
     c->chunk_ms = 0; c->chunk_steps = 0; c->chunk_count = 0;
+    return ESIM_OK;
+}
+
+extern "C" int esim_enable_chunk_kernel_timing(esim_ctx *ctx, int enable)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c) return ESIM_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->kdetail = enable != 0;
+    c->kd_used = 0;
+    for (int i = 0; i < ESIM_CK_N; ++i) { c->kd_ms[i] = 0; c->kd_calls[i] = 0; }
+    return ESIM_OK;
+}
+
+extern "C" int esim_chunk_kernel_timings(esim_ctx *ctx, double ms[ESIM_CK_N], uint64_t calls[ESIM_CK_N])
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c || !ms || !calls) return ESIM_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->P.device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    kd_resolve(c);
+    for (int i = 0; i < ESIM_CK_N; ++i) { ms[i] = c->kd_ms[i]; calls[i] = c->kd_calls[i]; c->kd_ms[i] = 0; c->kd_calls[i] = 0; }
     return ESIM_OK;
 }
 

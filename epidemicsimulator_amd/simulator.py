@@ -138,6 +138,7 @@ class Simulator:
                     self._progress(start)
                     start = time.time()
         else:
+            self.enable_chunk_kernel_timing(True)       # feeds the phase keys of timings.json (below); off again when simulate() returns
             while self._steps < max_time_step:
                 # the next progress line follows the step with index 0 (mod 50)
                 done = self._steps
@@ -147,16 +148,26 @@ class Simulator:
                 arr = self.run(n, stop_when_done=True)
                 if len(arr) == 0:
                     break
-                # the phases of simulator.rs:137-143 do not exist separately in a device-resident run: only the total is
-                # known (the block's wall time spread over its steps), so the phase keys are left out of those entries
+                # The phases of simulator.rs:137-143 do not exist separately in a device-resident run: a chunk pass works on up to
+                # 96 steps at once.  Their keys are APPORTIONED: the device time of the block's chunk kernels (HIP events in front of
+                # every kernel, esim_chunk_kernel_timings) by kernel -- marks + fold -> "Generate Exposures", draw + units -> "Apply
+                # Exposures", plan / decisions / counts / books / scatter -> "Apply Interventions" -- spread evenly over the block's
+                # steps; "total" is the block's wall time spread the same way.  Blocks whose steps ran in the sequential form (the step
+                # that starts the vaccination programme) carry "total" only.
                 per_step = (time.time() - t_block) / len(arr)
-                self.statistics_recorder.timer_entries.extend({"total": per_step} for _ in range(len(arr)))
+                entry = {"total": per_step}
+                phases = self.chunk_phase_seconds()
+                if sum(phases.values()) > 0.0:
+                    entry = dict({k: v / len(arr) for k, v in phases.items()}, total=per_step)
+                self.statistics_recorder.timer_entries.extend(dict(entry) for _ in range(len(arr)))
                 self.last = {k: int(arr[k][-1]) for k in arr.dtype.names}
                 if not self.last["disease_exists"]:
                     break
                 if (self._steps - 1) % DEBUG_ITERATION_PRINT == 0:
                     self._progress(start)
                     start = time.time()
+        if not self.record_timings:
+            self.enable_chunk_kernel_timing(False)
         self.statistics_recorder.dump_to_file(output_name, self.exposures_per_output_area(self.area_codes))
 
     def _progress(self, start):
@@ -344,6 +355,23 @@ class Simulator:
         ms, n = C.c_double(0), C.c_uint64(0)
         _lib.check(self.lib.esim_small_kernel_timing(self._ctx, C.byref(ms), C.byref(n)), self._ctx)
         return {"k_small_ms": ms.value, "steps": n.value}
+
+    def enable_chunk_kernel_timing(self, on=True):
+        _lib.check(self.lib.esim_enable_chunk_kernel_timing(self._ctx, int(on)), self._ctx)
+
+    def chunk_kernel_timings(self):
+        """Device milliseconds and launches per kernel of the chunk pass since the last call (esim_chunk_kernel_timings)."""
+        n = len(_lib.CHUNK_KERNELS)
+        ms, calls = (C.c_double * n)(), (C.c_uint64 * n)()
+        _lib.check(self.lib.esim_chunk_kernel_timings(self._ctx, ms, calls), self._ctx)
+        return {k: {"ms": ms[i], "calls": int(calls[i])} for i, k in enumerate(_lib.CHUNK_KERNELS)}
+
+    def chunk_phase_seconds(self):
+        """The same grouped under the reference's three timer labels (simulator.rs:137,140,143), in seconds."""
+        out = {"Generate Exposures": 0.0, "Apply Exposures": 0.0, "Apply Interventions": 0.0}
+        for k, v in self.chunk_kernel_timings().items():
+            out[_lib.PHASE_OF_KERNEL.get(k, "Apply Interventions")] += v["ms"] * 1e-3
+        return out
 
     def enable_phase_timing(self, on=True):
         _lib.check(self.lib.esim_enable_phase_timing(self._ctx, int(on)), self._ctx)

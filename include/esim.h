@@ -212,6 +212,15 @@ int  esim_free_enqueue(esim_ctx *ctx);
 int  esim_free_collect(esim_ctx *ctx, uint32_t *n_done);
 int  esim_set_pipeline(esim_ctx *ctx, int level);
 int  esim_chunk_timing(esim_ctx *ctx, double *total_ms, uint64_t *steps, uint64_t *chunks);
+/* Device time of the chunk pass per KERNEL (HIP events in front of every kernel of a chunk on the context's stream, resolved at
+ * the read-back that ends a burst; a kernel's figure includes the boundary to the next one): accumulated ms and launches since
+ * the last call, indexed by ESIM_CK_*.  The reference's three phase timers (simulator.rs:137-143) map onto them as
+ * "Generate Exposures" = marks + fold, "Apply Exposures" = draw + units, "Apply Interventions" = everything else (plan,
+ * decisions, counts, books, scatter) -- apportioned: a chunk pass works on up to 96 steps at once. */
+enum { ESIM_CK_MARKS = 0, ESIM_CK_FOLD, ESIM_CK_DRAW, ESIM_CK_UNITS, ESIM_CK_COUNT, ESIM_CK_BOOKS, ESIM_CK_SCATTER, ESIM_CK_VAX, ESIM_CK_VAX_ADJ,
+       ESIM_CK_VAX_FINAL, ESIM_CK_DECIDE, ESIM_CK_FUTURE, ESIM_CK_N };
+int  esim_enable_chunk_kernel_timing(esim_ctx *ctx, int enable);
+int  esim_chunk_kernel_timings(esim_ctx *ctx, double ms[ESIM_CK_N], uint64_t calls[ESIM_CK_N]);
 /* Steps run as time-parallel chunks under a vaccination programme (pipeline level 3: the chunk's vaccinations are planned
  * ahead, simulator.rs:524-553 being a pure function of the step and of citizens_eligible_for_vaccine), and how many of those
  * chunks were cut short because a citizen the plan had chosen left the eligible set on a bus first (simulator.rs:447-449). */

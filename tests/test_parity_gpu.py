@@ -349,6 +349,12 @@ def test_simulate_device_resident_blocks(tmp_path, capsys):
     assert [e["time_step"] for e in stats] == list(range(1, 132))
     timings = json.load(open(out + "timings.json"))
     assert len(timings) == 130 and all(t["total"] > 0 for t in timings)
+    # the reference's three phase keys (simulator.rs:137-143 -> timings.json) in a device-resident run: apportioned from the
+    # chunk kernels' HIP events (marks + fold / draw + units / the rest); every block that ran as chunk passes carries them
+    phased = [t for t in timings if len(t) > 1]
+    assert len(phased) >= 100
+    assert all(set(t) == {"Generate Exposures", "Apply Exposures", "Apply Interventions", "total"} for t in phased)
+    assert all(t["Generate Exposures"] > 0 and t["Apply Exposures"] > 0 and t["Apply Interventions"] > 0 for t in phased)
     assert len(json.load(open(out + "memory.json"))) == 130
     sim.close()
     # an epidemic that dies out stops the loop at the same step as the reference's `if !self.step() { break }`

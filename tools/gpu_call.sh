@@ -17,6 +17,12 @@ for step in "$@"; do
           timeout -k 10 300 python tools/wave_profile_units.py uk64m 2880 3360 3840 > gpurun_out/waveu_$tag.log 2>&1; rc=$?; tail -12 gpurun_out/waveu_$tag.log; [ $rc -eq 0 ] || exit $rc ;;
     fuzz) timeout -k 10 300 python tools/fuzz_parity.py 2000 80 > gpurun_out/fuzz_$tag.log 2>&1; rc=$?; tail -2 gpurun_out/fuzz_$tag.log; [ $rc -eq 0 ] || exit $rc
           ESIM_GRID_CHUNK=16 timeout -k 10 300 python tools/fuzz_parity.py 12000 20 --big > gpurun_out/fuzz_g16_$tag.log 2>&1; rc=$?; tail -1 gpurun_out/fuzz_g16_$tag.log; [ $rc -eq 0 ] || exit $rc ;;
+    grid16) echo -n "grid 1024: "; timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-extra-runs --cpu-seconds 0 | python -c "import sys,json; d=json.loads(sys.stdin.read()); t=d['config']['timed_region']; print(t['wall_us_per_step']*20, t['chunk_passes_device_ms']*1e3)" || exit 6
+            echo -n "grid 16:   "; ESIM_GRID_CHUNK=16 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-extra-runs --cpu-seconds 0 | python -c "import sys,json; d=json.loads(sys.stdin.read()); t=d['config']['timed_region']; print(t['wall_us_per_step']*20, t['chunk_passes_device_ms']*1e3)" || exit 6
+            echo -n "grid 64:   "; ESIM_GRID_CHUNK=64 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-extra-runs --cpu-seconds 0 | python -c "import sys,json; d=json.loads(sys.stdin.read()); t=d['config']['timed_region']; print(t['wall_us_per_step']*20, t['chunk_passes_device_ms']*1e3)" || exit 6
+            echo -n "york grid 1024: "; timeout -k 10 300 python tools/run_preset.py york | grep us/step | cut -c1-140
+            echo -n "york grid 64:   "; ESIM_GRID_CHUNK=64 timeout -k 10 300 python tools/run_preset.py york | grep us/step | cut -c1-140
+            echo -n "york grid 16:   "; ESIM_GRID_CHUNK=16 timeout -k 10 300 python tools/run_preset.py york | grep us/step | cut -c1-140 ;;
     *) echo "unknown step $step"; exit 9 ;;
   esac
 done
