@@ -743,6 +743,7 @@ namespace {
 int run_sequential(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_t *executed)
 {
     Dev &d = c->d;
+    c->ctrl_fresh = false;                   // (whatever a burst read back is out of date once more steps are enqueued)
     uint32_t remaining = n_steps, total = 0;
     int rc;
     while (remaining > 0) {
@@ -854,6 +855,7 @@ void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
 int run_chunk(esim_ctx_impl *c, uint32_t n_ahead, uint32_t *executed, Ctrl *state_before)
 {
     Dev &d = c->d;
+    c->ctrl_fresh = false;
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, n_ahead, c->P.max_steps, c->time_parallel ? 1 : 0, 0);
     Ctrl h;
     HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -1054,6 +1056,9 @@ extern "C" int esim_run(esim_ctx *ctx, uint32_t n_steps, int stop_when_done, esi
     else if ((rc = read_ctrl(c, &h))) return rc;
     if (h.error) return fail(c, -(int)h.error, "device-side error (S underflow / vaccination window exhausted)");
     const uint32_t done = h.steps_done >= first ? h.steps_done - first + 1 : 0;
+    if (std::getenv("ESIM_DEBUG"))
+        std::fprintf(stderr, "[esim] esim_run(%u steps from %u): done %u, t=%u steps_done=%u finished=%u chunk_ok=%u parallel=%u, records mirrored %u, control block %s\n",
+                     n_steps, first, done, h.t, h.steps_done, h.finished, h.chunk_ok, h.chunk_parallel, c->pin_valid, c->ctrl_fresh ? "from the burst" : "read now");
     c->host_t = first + done;
     if (out_array && done) {
         const uint32_t have = std::min(c->pin_valid, done);
