@@ -285,7 +285,7 @@ def main():
         dev_ms = sum(v["ms"] for v in kt.values())
         dom = max(kt, key=lambda k: kt[k]["ms"])
         pk = prof["kernels"].get("k_chunk_" + dom) or prof["kernels"].get("k_" + dom)
-        if pk and kt[dom]["calls"]:
+        if pk and kt[dom]["calls"] and "hbm_bytes_exact" in pk:      # (a round-3 profile summary: profiles/summarize_r03.py)
             dur_s = kt[dom]["ms"] * 1e-3 / kt[dom]["calls"]                      # live average launch duration
             hbm_bytes = pk["hbm_bytes_exact"] / pk["calls"]
             valu_cyc = pk["SQ_ACTIVE_INST_VALU"] * 4.0 / pk["calls"]             # SIMD-cycles with a VALU instruction active, per launch

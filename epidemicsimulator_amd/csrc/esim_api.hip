@@ -52,6 +52,7 @@ struct esim_ctx_impl {
     bool time_parallel = true;         // draw all steps of a chunk in one pass when its marks fit the hash map
     hipEvent_t cev[2] = { nullptr, nullptr }; double chunk_ms = 0; uint64_t chunk_steps = 0, chunk_count = 0;
     uint32_t grid_chunk = 1024;
+    uint32_t draw_mult = 4, units_mult = 4;   // k_chunk_draw / k_chunk_units run this many times the marks grid: more, shorter wavefronts than the chip holds at once
     bool pipeline = true;              // run chunks of steps as one kernel per step while no vaccination programme runs
     bool vax_chunks = true;            // time-parallel chunks also under a vaccination programme (their vaccinations planned ahead, k_chunk_vax)
     uint64_t vax_chunk_steps = 0, vax_chunk_cuts = 0;
@@ -364,7 +365,6 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     d.n = N; d.n_global = n_global; d.id_base = pop->citizen_id_base; d.n_bld = B; d.n_room = R;
     d.n_pt = (uint32_t)riders.size(); d.n_routes = n_routes; c->n_routes = n_routes;
     d.max_route = max_route;
-    d.draw_dynamic = std::getenv("ESIM_DRAW_STATIC") ? 0u : 1u;
     int rc;
     if ((rc = dev_alloc(c, &d.cit, (size_t)N + 1))) return rc;
     if ((rc = dev_upload(c, &d.home, pop->home_building, N))) return rc;
@@ -547,6 +547,8 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     c->grid_expose = 1024;
     if (const char *e = std::getenv("ESIM_GRID_INFECTED")) c->grid_infected = (uint32_t)std::max(1, std::atoi(e));   // tuning knobs
     if (const char *e = std::getenv("ESIM_GRID_CHUNK")) c->grid_chunk = (uint32_t)std::min((int)(CHUNK_WAVES_MAX * 64u / TPB), std::max(16, std::atoi(e) / 16 * 16));   // whole groups of 64 wavefronts
+    if (const char *e = std::getenv("ESIM_DRAW_MULT")) c->draw_mult = (uint32_t)std::min(16, std::max(1, std::atoi(e)));
+    if (const char *e = std::getenv("ESIM_UNITS_MULT")) c->units_mult = (uint32_t)std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("ESIM_GRID_EXPOSE")) c->grid_expose = (uint32_t)std::max(1, std::atoi(e));
     c->uploaded = true;
     return esim_reset(ctx);
@@ -808,9 +810,9 @@ void enqueue_parallel_chunk(esim_ctx_impl *c, int then_next, uint32_t limit_t)
     kd_mark(c, ESIM_CK_FOLD);
     hipLaunchKernelGGL(k_chunk_fold, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     kd_mark(c, ESIM_CK_DRAW);
-    hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk * c->draw_mult), dim3(TPB), 0, c->stream, d, c->grid_chunk * (TPB / 64u));
     kd_mark(c, ESIM_CK_UNITS);
-    hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk * c->units_mult), dim3(TPB), 0, c->stream, d);
     if (!small) { kd_mark(c, ESIM_CK_COUNT); hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d); }
     kd_mark(c, ESIM_CK_BOOKS);
     hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, small ? 1 : 0, then_next, (uint32_t)c->xf_n, limit_t);
@@ -835,9 +837,9 @@ void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
     kd_mark(c, ESIM_CK_FOLD);
     hipLaunchKernelGGL(k_chunk_fold, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     kd_mark(c, ESIM_CK_DRAW);
-    hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk * c->draw_mult), dim3(TPB), 0, c->stream, d, c->grid_chunk * (TPB / 64u));
     kd_mark(c, ESIM_CK_UNITS);
-    hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk * c->units_mult), dim3(TPB), 0, c->stream, d);
     kd_mark(c, ESIM_CK_COUNT);
     hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
     kd_mark(c, ESIM_CK_BOOKS);
@@ -1364,8 +1366,8 @@ int enqueue_sharded_chunk(esim_ctx_impl *c, uint32_t limit_t, bool vax)
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 1);
     hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_fold, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
-    hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
-    hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk * c->draw_mult), dim3(TPB), 0, c->stream, d, c->grid_chunk * (TPB / 64u));
+    hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk * c->units_mult), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
     if (vax && (rc = exchange_buf(c, 5, d.xc, FREE_MAX + 2u))) return rc;
     hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, 0, 0, (uint32_t)c->xf_n, limit_t);

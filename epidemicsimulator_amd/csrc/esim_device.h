@@ -196,7 +196,6 @@ struct Dev {
     uint32_t *hot;              // [HOT_COUNT * HOT_STRIDE] the counters of the lists above
     uint32_t *cursor;           // [EXP_ROWS][FREE_MAX] write cursors into each step's stretch of the log, a row per EXP_ROWS-th workgroup
     uint32_t max_route;         // riders of the largest route
-    uint32_t draw_dynamic;      // k_chunk_draw hands the last items out in blocks (ESIM_DRAW_STATIC=1 turns it off: A/B runs)
     // vaccination inside time-parallel chunks
     uint32_t *vax_ev;           // [FREE_MAX][VACC_MAX_RATE] citizens chosen in each step of the chunk, in candidate order
     uint32_t *vax_cnt;          // [FREE_MAX] how many (this shard's)
@@ -264,14 +263,9 @@ struct Dev {
 #define HOT_UNITS 64u              // [SUBQ] deferred units, by producing wavefront & 63
 #define HOT_BIGPAIRS 128u          // (route, bus step) pairs of routes with more than 64 riders
 #define HOT_BIG 129u               // [SUBQ] slots listed for k_chunk_fold, by listing wavefront & 63
-#define HOT_DRAWQ 193u             // [DRAW_POOLS] blocks of items handed out from each pool of k_chunk_draw's dynamic part
-#define HOT_PREV_NEWEXP 201u       // [SUBQ] copy of HOT_NEWEXP of the chunk whose log entries k_chunk_scatter is writing
-#define HOT_RESET 201u             // counters k_decide zeroes for a new chunk
-#define HOT_COUNT 265u
-#define DRAW_POOLS 8u
-#define DRAW_BLOCK 16u             // items per block of the dynamic part
-#define DRAW_STATIC_16THS 11u      // sixteenths of the items dealt as fixed stretches
-#define DRAW_DYNAMIC_MIN 16u       // items per wavefront from which the dynamic part is used
+#define HOT_PREV_NEWEXP 193u       // [SUBQ] copy of HOT_NEWEXP of the chunk whose log entries k_chunk_scatter is writing
+#define HOT_RESET 193u             // counters k_decide zeroes for a new chunk
+#define HOT_COUNT 257u
 #define UNIT_NOOP 0xFFFFFFFFu
 #define CHUNK_BUS_STEPS 8u         // a one-pass chunk has at most this many steps with riders on a bus
 #define COUNT_GRID 256u            // workgroups of k_chunk_count

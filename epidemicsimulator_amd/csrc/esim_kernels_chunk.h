@@ -1249,7 +1249,7 @@ __device__ __forceinline__ bool item_ok(const Dev &d, const ItemFetch &it)
 }
 #define PAIR_SPREAD 1237u
 // apply_exposures (simulator.rs:262-405) for every item and every step of the chunk.
-__global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
+__global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
 {
     __shared__ ChunkShared sm;
     __shared__ WaveScratch wsc[TPB / 64];
@@ -1265,38 +1265,35 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     // reaches a key first claims its item, so the early wavefronts hold far more items than the late ones.  The pass
     // therefore takes the items in id order as ONE dense sequence and every wavefront draws an equal stretch of it
     // (k_chunk_fold left the prefix sums of used_cnt in used_pref).
+    // n_mw = wavefronts of k_chunk_marks (whose id ranges the items sit in); this kernel's own grid is a multiple of that:
+    // equal stretches are equal in ITEMS, not in work -- 20 to 40 items per wavefront with member lists of 2 to 200, then the
+    // wavefront's share of the routes: in round 2 the slowest of 4096 wavefronts ran 1.4x (items) and 2x (routes) the median,
+    // and 2.8 of the 4 wavefronts a SIMD had been given were resident on average.  Taking blocks from shared counters does
+    // not help at 20 items per wavefront (measured: +-0); what does is MORE, SHORTER wavefronts than the chip holds at once
+    // (ESIM_DRAW_MULT x the marks grid): the dispatcher starts the next workgroup where one has finished.
     const uint32_t per_wave = ld(&ctrl->items_per_wave);
-    if ((unsigned long long)per_wave * n_waves > d.items_cap) return;          // (k_chunk_marks raised ESIM_ERANGE and left no items)
-    // Equal stretches are equal in ITEMS, not in work: a few hundred items per wavefront with member lists of 2 to 200 leave
-    // the slowest of 4096 wavefronts ~35 % behind the mean (r02: 2.8 of 4 wavefronts resident per SIMD over the launch).  So
-    // only the first DRAW_STATIC_16THS / 16 of the items are dealt as fixed stretches; the rest is DRAW_POOLS pools of blocks of
-    // DRAW_BLOCK items that the wavefronts take as they finish (one returning atomic per block, a counter per pool: a single
-    // word saturates at ~88 dequeues / us, MI355X_MICROARCH.md "dequeue"; a wavefront starts with pool `wave % DRAW_POOLS`).
-    // Chunks of few items keep the fixed stretches alone: their time is latency, not balance.
-    const uint32_t T = d.used_pref[n_waves];
-    const uint32_t coarse = d.used_pref[min(64u * lane, n_waves)];
-    const bool dynamic = d.draw_dynamic && T >= DRAW_DYNAMIC_MIN * n_waves;
-    const uint32_t T_static = dynamic ? (uint32_t)(((unsigned long long)T * DRAW_STATIC_16THS) >> 4) : T;
-    const uint32_t Tq = T_static / n_waves, Tr = T_static % n_waves;           // (T_static * wave / n_waves without 64-bit division)
-    uint32_t d_lo = Tq * wave + Tr * wave / n_waves, d_hi = Tq * (wave + 1u) + Tr * (wave + 1u) / n_waves;
-    const uint32_t pool_sz = (T - T_static + DRAW_POOLS - 1u) / DRAW_POOLS;     // items per pool (the last one may be shorter)
-    uint32_t pool = wave % DRAW_POOLS, pools_tried = 0u;
+    if ((unsigned long long)per_wave * n_mw > d.items_cap || n_waves % n_mw != 0u) return;   // (k_chunk_marks raised ESIM_ERANGE and left no items)
+    const uint32_t G = n_waves / n_mw;
+    const uint32_t T = d.used_pref[n_mw];
+    const uint32_t coarse = d.used_pref[min(64u * lane, n_mw)];
+    const uint32_t Tq = T / n_waves, Tr = T % n_waves;                         // (T * wave / n_waves without 64-bit division)
+    const uint32_t d_lo = Tq * wave + (uint32_t)(((unsigned long long)Tr * wave) / n_waves), d_hi = Tq * (wave + 1u) + (uint32_t)(((unsigned long long)Tr * (wave + 1u)) / n_waves);
     // the wavefront of k_chunk_marks that owns dense index i: the last one whose ids start at or before it -- first among
-    // every 64th (`coarse`, kept for the whole kernel), then among the 64 from there on (`win`: lane l holds where the ids of owner
-    // ow_base + l start; a window of 64 owners, moved on when used up)
+    // every 64th (`coarse`), then among the 64 from there on (`win`: lane l holds where the ids of owner ow_base + l start; a
+    // window of 64 owners, moved on when used up)
     uint32_t ow_base = 0u, win = 0u, ow = 0u;
     auto seek = [&](uint32_t i) {
-        ow_base = 64u * ((uint32_t)__popcll(__ballot(64u * lane < n_waves && coarse <= i)) - 1u);
-        win = d.used_pref[min(ow_base + lane, n_waves)];
-        ow = ow_base + (uint32_t)__popcll(__ballot(ow_base + lane < n_waves && win <= i)) - 1u;
+        ow_base = 64u * ((uint32_t)__popcll(__ballot(64u * lane < n_mw && coarse <= i)) - 1u);
+        win = d.used_pref[min(ow_base + lane, n_mw)];
+        ow = ow_base + (uint32_t)__popcll(__ballot(ow_base + lane < n_mw && win <= i)) - 1u;
     };
     seek(d_lo);
     // item id of dense index i; called with ascending i
     auto id_of = [&](uint32_t i) -> uint32_t {
         for (;;) {
             const uint32_t rel = ow - ow_base;
-            if (rel == 63u) { ow_base = ow; win = d.used_pref[min(ow_base + lane, n_waves)]; continue; }
-            if (ow + 1u < n_waves && (uint32_t)__builtin_amdgcn_readlane((int)win, (int)(rel + 1u)) <= i) { ++ow; continue; }
+            if (rel == 63u) { ow_base = ow; win = d.used_pref[min(ow_base + lane, n_mw)]; continue; }
+            if (ow + 1u < n_mw && (uint32_t)__builtin_amdgcn_readlane((int)win, (int)(rel + 1u)) <= i) { ++ow; continue; }
             return ow * per_wave + (i - (uint32_t)__builtin_amdgcn_readlane((int)win, (int)rel));
         }
     };
@@ -1306,13 +1303,20 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
     if (d_lo + 1u < d_hi) id_nxt = fetch_item(d, id_of(d_lo + 1u), lane);
     // ... and the first look at the (route, bus step) pairs dealt to this wavefront (phase 2 below), so that they are here
     // when the items are done
+    // Wavefront w of k_chunk_marks left pair_cnt[w] pairs in its own stretch of K places.  Its k-th pair goes to the wavefront
+    // of this kernel with number ((w + k * PAIR_SPREAD) mod n_mw) + n_mw * (k mod G): lane l of wavefront (base, r) looks at
+    // k = l * G + r of the stretch it may have been dealt from.
     const uint32_t K = 2u * per_wave;                                          // pairs a stretch of the list can hold
+    const uint32_t w_base = wave % n_mw, w_rep = wave / n_mw;
     uint32_t code_l = 0u, off_l = 0u, sz_l = 0u;
     bool have = false;
-    if (lane < K) {
-        const uint32_t src = (wave + n_waves - (uint32_t)(((unsigned long long)lane * PAIR_SPREAD) % n_waves)) % n_waves;
-        code_l = d.route_pairs[(size_t)src * K + lane];                       // in bounds whether or not the pair exists
-        have = lane < d.pair_cnt[src] && (code_l >> 7) < d.n_routes && (code_l & 127u) < n;
+    {
+        const uint32_t k = lane * G + w_rep;
+        if (k < K) {
+            const uint32_t src = (w_base + n_mw - (uint32_t)(((unsigned long long)k * PAIR_SPREAD) % n_mw)) % n_mw;
+            code_l = d.route_pairs[(size_t)src * K + k];                      // in bounds whether or not the pair exists
+            have = k < d.pair_cnt[src] && (code_l >> 7) < d.n_routes && (code_l & 127u) < n;
+        }
     }
     for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
     for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
@@ -1331,8 +1335,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
 #endif
     uint32_t pst[5] = { 0u, 0u, 0u, 0u, 0u };
     const uint32_t pt1 = PROF_NOW();
-    // (1) buildings and school rooms: one wavefront per item; the fixed stretch first, then blocks from the pools
-    for (;;) {
+    // (1) buildings and school rooms: one wavefront per item
     for (uint32_t v = d_lo; v < d_hi; ++v) {
         const uint32_t x = merge_fetch(id_cur, sl_cur, lane);
         id_cur = id_nxt;
@@ -1381,37 +1384,17 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d)
         __builtin_amdgcn_wave_barrier();
         { const uint32_t dt = PROF_NOW() - pi0; p_item_max = dt > p_item_max ? dt : p_item_max; }
     }
-    // the next block: from this wavefront's pool while it lasts, then from the others in turn
-    if (!dynamic) break;
-    bool got = false;
-    while (pools_tried < DRAW_POOLS) {
-        const uint32_t p_lo = T_static + pool * pool_sz, p_hi = min(T, p_lo + pool_sz);
-        uint32_t blk = 0u;
-        if (lane == 0) blk = p_lo < p_hi ? atomicAdd(&d.hot[(HOT_DRAWQ + pool) * HOT_STRIDE], 1u) : 0xFFFFFFu;
-        blk = FX(blk, 0);
-        const unsigned long long lo64 = (unsigned long long)p_lo + (unsigned long long)blk * DRAW_BLOCK;
-        if (lo64 < p_hi) { d_lo = (uint32_t)lo64; d_hi = min(p_hi, d_lo + DRAW_BLOCK); got = true; break; }
-        pool = pool + 1u == DRAW_POOLS ? 0u : pool + 1u; ++pools_tried;      // this pool is used up (for good: its counter only grows)
-    }
-    if (!got) break;
-    seek(d_lo);
-    id_cur = fetch_item(d, id_of(d_lo), lane);
-    if (d_lo + 1u < d_hi) id_nxt = fetch_item(d, id_of(d_lo + 1u), lane);
-    sl_cur = fetch_slot(d, FX(id_cur, LANE_HSLOT), lane);
-    }
     const uint32_t pt2 = PROF_NOW();
     // (2) routes of <= 64 riders: one wavefront per (route, bus step) with an Infected rider; rank by (Philox key, id)
     // with shuffles, buses are runs of bus_capacity ranks (simulator.rs:362-388)
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
-    // Wavefront w of k_chunk_marks left pair_cnt[w] pairs in its own stretch of the list.  They are dealt out so that the
-    // k-th pair of w goes to wavefront (w + k * PAIR_SPREAD) mod n_waves: here lane k looks at the stretch it may have
-    // been dealt from, and the wavefront then takes the pairs that exist one by one.
-    for (uint32_t k0 = 0; k0 < K; k0 += 64u) {
+    // (the pairs dealt to this wavefront -- see the first look above --, taken one by one)
+    for (uint32_t k0 = 0; k0 * G < K; k0 += 64u) {
         if (k0) {                                                             // (beyond the 64 looked at up front: many Infected)
-            const uint32_t kk = k0 + lane;
+            const uint32_t kk = (k0 + lane) * G + w_rep;
             have = false;
             if (kk < K) {
-                const uint32_t src = (wave + n_waves - (uint32_t)(((unsigned long long)kk * PAIR_SPREAD) % n_waves)) % n_waves;
+                const uint32_t src = (w_base + n_mw - (uint32_t)(((unsigned long long)kk * PAIR_SPREAD) % n_mw)) % n_mw;
                 code_l = d.route_pairs[(size_t)src * K + kk];
                 have = kk < d.pair_cnt[src] && (code_l >> 7) < d.n_routes && (code_l & 127u) < n;
             }
