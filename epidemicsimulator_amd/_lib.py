@@ -181,7 +181,7 @@ def load():
 
 
 ESIM_OK, ESIM_ERANGE = 0, -5          # include/esim.h
-CHUNK_KERNELS = ("marks", "fold", "draw", "units", "count", "books", "scatter", "vax", "vax_adj", "vax_final", "decide", "future")   # ESIM_CK_*
+CHUNK_KERNELS = ("marks", "fold", "draw", "units", "count", "books", "scatter", "vax", "vax_adj", "vax_final", "decide", "future", "map_clear")   # ESIM_CK_*
 PHASE_OF_KERNEL = {"marks": "Generate Exposures", "fold": "Generate Exposures", "draw": "Apply Exposures", "units": "Apply Exposures"}   # the rest: "Apply Interventions"
 
 

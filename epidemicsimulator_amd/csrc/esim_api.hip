@@ -52,6 +52,10 @@ struct esim_ctx_impl {
     bool time_parallel = true;         // draw all steps of a chunk in one pass when its marks fit the hash map
     hipEvent_t cev[2] = { nullptr, nullptr }; double chunk_ms = 0; uint64_t chunk_steps = 0, chunk_count = 0;
     uint32_t grid_chunk = 1024;
+    // persistent item map (unsharded contexts): the host's view of it -- valid as long as nothing but map-maintaining chunk passes
+    // has been enqueued since it was (re)built; a rebuild every pmap_rebuild_every chunks sheds the items of the recovered
+    bool pmap = true, map_valid = false, pmap_used = false;
+    uint32_t pmap_since_rebuild = 0, pmap_rebuild_every = 4;
     uint32_t draw_mult = 4, units_mult = 4;   // k_chunk_draw / k_chunk_units run this many times the marks grid: more, shorter wavefronts than the chip holds at once
     bool pipeline = true;              // run chunks of steps as one kernel per step while no vaccination programme runs
     bool vax_chunks = true;            // time-parallel chunks also under a vaccination programme (their vaccinations planned ahead, k_chunk_vax)
@@ -433,7 +437,9 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
             for (size_t i = 0; i < res_off.size(); ++i) ovf_off[i] = res_off[i] + wrk_off[i];
             if ((rc = dev_upload(c, &d.ovf_off, ovf_off.data(), ovf_off.size()))) return rc;
             d.ovf_room_base = ovf_off.back();
-            d.ovf_n = d.ovf_room_base + room_off.back() + 1u;
+            // (the persistent map keeps two places per member -- a record and a cancellation -- and the routes' riders behind the rooms)
+            d.ovf_route_base = d.ovf_room_base + room_off.back();
+            d.ovf_n = 2u * (d.ovf_route_base + (uint32_t)riders.size()) + 2u;
             if ((rc = dev_alloc(c, &d.ovf, (size_t)d.ovf_n))) return rc;
             HIP_TRY(c, hipMemset(d.ovf, 0, sizeof(uint32_t) * (size_t)d.ovf_n));
         }
@@ -441,6 +447,10 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         d.big_qcap = d.items_cap / SUBQ;             // (a slot is listed at most once a chunk, and there are at most items_cap of them)
         if ((rc = dev_alloc(c, &d.big_list, (size_t)d.big_qcap * SUBQ * 3u))) return rc;
         if ((rc = dev_alloc(c, &d.used_pref, CHUNK_WAVES_MAX + 1u))) return rc;
+        if ((rc = dev_alloc(c, &d.pbig_cnt, SUBQ))) return rc;
+        if ((rc = dev_alloc(c, &d.neg_list, (size_t)NEG_CAP * 2u))) return rc;
+        HIP_TRY(c, hipMemset(d.pbig_cnt, 0, sizeof(uint32_t) * SUBQ));
+        HIP_TRY(c, hipMemset(d.neg_list, 0, sizeof(uint32_t) * (size_t)NEG_CAP * 2u));
         HIP_TRY(c, hipMemset(d.big_list, 0, sizeof(uint32_t) * (size_t)d.big_qcap * SUBQ * 3u));
         HIP_TRY(c, hipMemset(d.used_pref, 0, sizeof(uint32_t) * (CHUNK_WAVES_MAX + 1u)));
         if ((rc = dev_alloc(c, &d.pair_cnt, 16384u))) return rc;
@@ -547,6 +557,8 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     c->grid_expose = 1024;
     if (const char *e = std::getenv("ESIM_GRID_INFECTED")) c->grid_infected = (uint32_t)std::max(1, std::atoi(e));   // tuning knobs
     if (const char *e = std::getenv("ESIM_GRID_CHUNK")) c->grid_chunk = (uint32_t)std::min((int)(CHUNK_WAVES_MAX * 64u / TPB), std::max(16, std::atoi(e) / 16 * 16));   // whole groups of 64 wavefronts
+    if (const char *e = std::getenv("ESIM_PMAP")) c->pmap = std::atoi(e) != 0;
+    if (const char *e = std::getenv("ESIM_PMAP_REBUILD")) c->pmap_rebuild_every = (uint32_t)std::max(1, std::atoi(e));
     if (const char *e = std::getenv("ESIM_DRAW_MULT")) c->draw_mult = (uint32_t)std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("ESIM_UNITS_MULT")) c->units_mult = (uint32_t)std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("ESIM_GRID_EXPOSE")) c->grid_expose = (uint32_t)std::max(1, std::atoi(e));
@@ -583,6 +595,7 @@ extern "C" int esim_reset(esim_ctx *ctx)
     HIP_TRY(c, hipMemcpy(d.log_off, off.data(), sizeof(uint32_t) * (TE_SLOTS + 1), hipMemcpyHostToDevice));
     if (n_seeds) HIP_TRY(c, hipMemcpy(d.log, c->init_log.data(), sizeof(uint32_t) * n_seeds, hipMemcpyHostToDevice));
     c->host_t = 1;
+    c->map_valid = false;                         // (the device arrays may still hold the last run's map: the first chunk clears them)
     c->stop_flag_dev = 0;
     c->pin_track = false;
     c->free_limit = 0;
@@ -746,6 +759,7 @@ int run_sequential(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, ui
 {
     Dev &d = c->d;
     c->ctrl_fresh = false;                   // (whatever a burst read back is out of date once more steps are enqueued)
+    c->map_valid = false;                    // (sequential steps do not maintain the persistent item map)
     uint32_t remaining = n_steps, total = 0;
     int rc;
     while (remaining > 0) {
@@ -801,18 +815,47 @@ void kd_resolve(esim_ctx_impl *c)
 // While few citizens are Infected the books, the log scatter, the clean-up and that preparation are ONE single-workgroup
 // kernel (a kernel boundary costs more than these steps); with many, the scatter and clean-up need the whole chip.
 // then_next: 0 nothing, 1 census ahead + decisions of the next chunk, 2 census ahead only.
+// marks -> fold -> draw -> units of one chunk: on the persistent item map (unsharded contexts; k_map_enter only enters who turns
+// Infected in the chunk, after a k_map_clear everybody who is Infected in it) or with the map rebuilt and torn down per chunk
+// (sharded contexts, ESIM_PMAP=0).
+void enqueue_chunk_front(esim_ctx_impl *c)
+{
+    Dev &d = c->d;
+    const bool pm = c->pmap && d.world == 1u;
+    if (pm) {
+        if (!c->map_valid || c->pmap_since_rebuild >= c->pmap_rebuild_every) {
+            kd_mark(c, ESIM_CK_MAP_CLEAR);
+            hipLaunchKernelGGL(k_map_clear, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
+            hipLaunchKernelGGL(k_map_reset, dim3(1), dim3(64), 0, c->stream, d);
+            c->pmap_since_rebuild = 0;
+        }
+        c->map_valid = true; c->pmap_used = true; c->pmap_since_rebuild++;
+        kd_mark(c, ESIM_CK_MARKS);
+        hipLaunchKernelGGL(k_map_enter, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+        kd_mark(c, ESIM_CK_FOLD);
+        hipLaunchKernelGGL(k_chunk_fold<true>, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+        kd_mark(c, ESIM_CK_DRAW);
+        hipLaunchKernelGGL(k_chunk_draw<true>, dim3(c->grid_chunk * c->draw_mult), dim3(TPB), 0, c->stream, d, SUBQ);
+        kd_mark(c, ESIM_CK_UNITS);
+        hipLaunchKernelGGL(k_chunk_units<true>, dim3(c->grid_chunk * c->units_mult), dim3(TPB), 0, c->stream, d);
+        return;
+    }
+    c->map_valid = false;
+    kd_mark(c, ESIM_CK_MARKS);
+    hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    kd_mark(c, ESIM_CK_FOLD);
+    hipLaunchKernelGGL(k_chunk_fold<false>, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    kd_mark(c, ESIM_CK_DRAW);
+    hipLaunchKernelGGL(k_chunk_draw<false>, dim3(c->grid_chunk * c->draw_mult), dim3(TPB), 0, c->stream, d, c->grid_chunk * (TPB / 64u));
+    kd_mark(c, ESIM_CK_UNITS);
+    hipLaunchKernelGGL(k_chunk_units<false>, dim3(c->grid_chunk * c->units_mult), dim3(TPB), 0, c->stream, d);
+}
+
 void enqueue_parallel_chunk(esim_ctx_impl *c, int then_next, uint32_t limit_t)
 {
     Dev &d = c->d;
     const bool small = c->last_chunk_pairs < 1024u;
-    kd_mark(c, ESIM_CK_MARKS);
-    hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
-    kd_mark(c, ESIM_CK_FOLD);
-    hipLaunchKernelGGL(k_chunk_fold, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
-    kd_mark(c, ESIM_CK_DRAW);
-    hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk * c->draw_mult), dim3(TPB), 0, c->stream, d, c->grid_chunk * (TPB / 64u));
-    kd_mark(c, ESIM_CK_UNITS);
-    hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk * c->units_mult), dim3(TPB), 0, c->stream, d);
+    enqueue_chunk_front(c);
     if (!small) { kd_mark(c, ESIM_CK_COUNT); hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d); }
     kd_mark(c, ESIM_CK_BOOKS);
     hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, small ? 1 : 0, then_next, (uint32_t)c->xf_n, limit_t);
@@ -828,18 +871,19 @@ void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
     Dev &d = c->d;
     kd_mark(c, ESIM_CK_VAX);
     hipLaunchKernelGGL(k_chunk_vax, dim3(FREE_MAX + 1u), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 0);   // (+ the census ahead)
+    // (persistent map: a rebuild has to be decided BEFORE the plan's cancellation records go into the map)
+    const bool pm = c->pmap && d.world == 1u;
+    if (pm && (!c->map_valid || c->pmap_since_rebuild >= c->pmap_rebuild_every)) {
+        kd_mark(c, ESIM_CK_MAP_CLEAR);
+        hipLaunchKernelGGL(k_map_clear, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
+        hipLaunchKernelGGL(k_map_reset, dim3(1), dim3(64), 0, c->stream, d);
+        c->pmap_since_rebuild = 0; c->map_valid = true;
+    }
     kd_mark(c, ESIM_CK_VAX_ADJ);
-    hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+    hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, pm ? 1 : 0);
     kd_mark(c, ESIM_CK_DECIDE);
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 0);
-    kd_mark(c, ESIM_CK_MARKS);
-    hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
-    kd_mark(c, ESIM_CK_FOLD);
-    hipLaunchKernelGGL(k_chunk_fold, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
-    kd_mark(c, ESIM_CK_DRAW);
-    hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk * c->draw_mult), dim3(TPB), 0, c->stream, d, c->grid_chunk * (TPB / 64u));
-    kd_mark(c, ESIM_CK_UNITS);
-    hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk * c->units_mult), dim3(TPB), 0, c->stream, d);
+    enqueue_chunk_front(c);
     kd_mark(c, ESIM_CK_COUNT);
     hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
     kd_mark(c, ESIM_CK_BOOKS);
@@ -1353,7 +1397,7 @@ int enqueue_sharded_chunk(esim_ctx_impl *c, uint32_t limit_t, bool vax)
         hipLaunchKernelGGL(k_vax_live, dim3(PLAN_W / TPB, FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
         if ((rc = exchange_buf(c, 3, d.xv, XV_HEADER + (size_t)FREE_MAX * (PLAN_W / 32u)))) return rc;
         hipLaunchKernelGGL(k_chunk_vax, dim3(FREE_MAX), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1);
-        hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+        hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 0);
     }
     const size_t seg = 1u + 3u * (size_t)d.xs_cap;
     HIP_TRY(c, hipMemsetAsync(d.xs + (size_t)d.rank * seg, 0, sizeof(uint32_t), c->stream));
@@ -1365,9 +1409,9 @@ int enqueue_sharded_chunk(esim_ctx_impl *c, uint32_t limit_t, bool vax)
     if ((rc = exchange(c, 2))) return rc;
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 1);
     hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
-    hipLaunchKernelGGL(k_chunk_fold, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
-    hipLaunchKernelGGL(k_chunk_draw, dim3(c->grid_chunk * c->draw_mult), dim3(TPB), 0, c->stream, d, c->grid_chunk * (TPB / 64u));
-    hipLaunchKernelGGL(k_chunk_units, dim3(c->grid_chunk * c->units_mult), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_fold<false>, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_draw<false>, dim3(c->grid_chunk * c->draw_mult), dim3(TPB), 0, c->stream, d, c->grid_chunk * (TPB / 64u));
+    hipLaunchKernelGGL(k_chunk_units<false>, dim3(c->grid_chunk * c->units_mult), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
     if (vax && (rc = exchange_buf(c, 5, d.xc, FREE_MAX + 2u))) return rc;
     hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, 0, 0, (uint32_t)c->xf_n, limit_t);
@@ -1414,6 +1458,12 @@ extern "C" int esim_run_sharded(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_don
     // different steps would issue different collectives): a flag an earlier esim_run left on the device is cleared
     static const uint32_t zero = 0u;
     HIP_TRY(c, hipMemcpyAsync(&d.ctrl->stop_when_done, &zero, sizeof zero, hipMemcpyHostToDevice, c->stream));
+    if (c->pmap_used) {                              // (a persistent map left by esim_run: the chunk pass of sharded runs builds its own per chunk)
+        hipLaunchKernelGGL(k_map_clear, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
+        hipLaunchKernelGGL(k_map_reset, dim3(1), dim3(64), 0, c->stream, d);
+        c->pmap_used = false;
+    }
+    c->map_valid = false;
     // (a communicator on an unsharded context -- one rank -- still makes its collectives: the sums over one rank change nothing,
     // which is how the RCCL path is exercised on a one-GPU box)
     const bool ex = d.n_shards > 1 || c->nccl || c->comm_fn;
@@ -1913,6 +1963,7 @@ extern "C" int esim_checkpoint_restore(esim_ctx *ctx, const void *buf, size_t by
     h.chunk_ok = 0; h.chunk_parallel = 0; h.chunk_done = 0; h.n_items = 0; h.n_newexp = 0; h.n_units = 0; h.unit_next = 0;
     h.n_route_pairs = 0; h.n_route_pairs_big = 0; h.prev_n_items = 0; h.prev_per_wave = 0; h.items_per_wave = 0; h.small_done = 0;
     h.free_base = 0; h.n_riders = 0; h.peer_error = 0;
+    h.map_t = 0; h.pmap_chunk = 0; h.prev_pmap = 0; h.n_neg = 0;        // (the item map is derived state: the next chunk rebuilds it)
     for (int z = 0; z < 5; ++z) h.counts[z] = 0;
     // marks of the last step are only ever cleared, never read, by the step after it: start without them
     for (uint32_t z = 0; z < MARK_SLOTS; ++z) { h.n_touched_bld[z] = 0; h.n_touched_room[z] = 0; h.n_touched_route[z] = 0; h.n_touched_route_big[z] = 0; }

@@ -11,6 +11,8 @@
 // bits 17..11  vax : only inside a time-parallel chunk that runs under a vaccination programme: 127 - j when the citizen
 //                   is set Vaccinated at the END of step j of the chunk (simulator.rs:524-553), 0 = not in this chunk.  The
 //                   earliest such step wins by atomicMax; k_chunk_scatter turns it into te = TE_VACCINATED and clears it.
+// bit  9       in_map : the persistent item map holds this citizen's records (set when it is entered, k_map_enter; meaningless while
+//                   Ctrl::map_t does not equal the chunk's first step: a rebuild clears the bits of everybody it may concern)
 // bit  10      plan_skip : the citizen is Susceptible and WILL be exposed on public transport in the step at ctrl->t (a chunk was
 //                   cut there, k_chunk_vax): it leaves citizens_eligible_for_vaccine in that step, so the next plan must not
 //                   choose it.  Any exposure drops the bit.
@@ -28,6 +30,7 @@
 #define CW_KEEP        (CW_FLAGS | CW_VAX_MASK)            // what an exposure inside a chunk leaves as it is
 #define CW_VAX_NONE    0xFFFFFFFFu
 #define CW_PLAN_SKIP   (1u << 10)
+#define CW_IN_MAP      (1u << 9)    // persistent item map (k_map_enter): the citizen's records have been entered into the items it stands in
 // step of the chunk at whose end the citizen becomes Vaccinated (CW_VAX_NONE: not in this chunk)
 #define CW_VAX_REL(w)  ((((w) >> CW_VAX_SHIFT) & 0x7Fu) ? 127u - (((w) >> CW_VAX_SHIFT) & 0x7Fu) : CW_VAX_NONE)
 #define CW_VAX_FIELD(j) ((127u - (j)) << CW_VAX_SHIFT)
@@ -104,6 +107,13 @@ struct Ctrl {
     uint32_t vax_planned, prev_planned; // steps the plan of the chunk in preparation / being finished covers (>= the chunk's length)
     uint32_t xs_need;           // sharded chunks: the most commuter records any shard wanted to send for the chunk last prepared
     uint32_t vax_fail;          // sharded plans: steps whose candidates beyond the exchanged window would have been needed (plan void)
+    // persistent item map: valid for a chunk that starts at step map_t -- every form that advances the clock
+    // without maintaining the map (sequential steps, k_pipe chunks, a restore) leaves map_t behind and so invalidates it
+    uint32_t map_t;
+    uint32_t chunk_e0;          // log entries [chunk_e0, chunk_i1): exposure steps that BECOME Infected in some step of the chunk (k_decide)
+    uint32_t n_neg;             // cancellation records appended for this chunk's plan (Dev::neg_list)
+    uint32_t pmap_chunk;        // the chunk in flight runs on the persistent map (k_map_enter decided)
+    uint32_t prev_pmap;         // ... and the chunk k_chunk_scatter is finishing did
     uint32_t peer_error;        // sharded runs: the error fields of ALL shards, summed (ERR_FIELD): every rank takes its return code
                                 // from this word, so that all leave esim_run_sharded together (k_status_unpack)
 };
@@ -186,6 +196,11 @@ struct Dev {
     uint32_t *ovf;              // [ovf_n = ovf_room_base + room_off[n_room] + 1]
     uint32_t ovf_n;
     uint32_t n_wrk_idx, n_room_idx;   // lengths of wrk_idx / room_idx (what a member range read from a chunk table is checked against)
+    // persistent item map: per-sub-list cursors of the slots listed for k_map_fold (those with records in `ovf`), the addresses of
+    // this chunk's cancellation records (so that those of uncommitted steps can be taken back)
+    uint32_t *pbig_cnt;         // [SUBQ]
+    uint32_t *neg_list;         // [NEG_CAP][2] word index (bit 31: in `ovf`, else in `slot_iv`), step of the chunk
+    uint32_t ovf_route_base;    // records of a route's Infected riders: ovf[2 * (ovf_route_base + route_off[r]) ...)
     uint32_t *big_list;         // [SUBQ][big_qcap][3] slots with records in `ovf`, where those start and how many fit, listed by the first
                                 // to put one there; 64 lists by listing wavefront & 63, lengths in hot[HOT_BIG ...]
     uint32_t big_qcap;
@@ -266,6 +281,7 @@ struct Dev {
 #define HOT_PREV_NEWEXP 193u       // [SUBQ] copy of HOT_NEWEXP of the chunk whose log entries k_chunk_scatter is writing
 #define HOT_RESET 193u             // counters k_decide zeroes for a new chunk
 #define HOT_COUNT 257u
+#define NEG_CAP (1u << 18)          // cancellation records per chunk (a chunk plans at most 96 x 8192 vaccinations, few of them of Infected citizens)
 #define UNIT_NOOP 0xFFFFFFFFu
 #define CHUNK_BUS_STEPS 8u         // a one-pass chunk has at most this many steps with riders on a bus
 #define COUNT_GRID 256u            // workgroups of k_chunk_count

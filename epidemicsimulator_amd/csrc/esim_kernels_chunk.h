@@ -219,6 +219,11 @@ __device__ __forceinline__ void decide_body(const Dev &d, uint32_t max_ahead, ui
         const int hi_te = (int)(t0 + n_ok + TE_BIAS) - (int)d.exposed_time - 2;
         ctrl->chunk_i0 = (hi_te < 0 || n_ok == 0u) ? 0u : ld(&d.log_off[lo_te < 0 ? 0 : lo_te]);
         ctrl->chunk_i1 = (hi_te < 0 || n_ok == 0u) ? 0u : ld(&d.log_off[hi_te + 1]);
+        // ... and of those that TURN Infected in it (exposure steps from the one whose stretch starts in step 0): what the
+        // persistent map has to enter
+        const int e_te = (int)(t0 + TE_BIAS) - (int)d.exposed_time - 1;
+        ctrl->chunk_e0 = (hi_te < 0 || n_ok == 0u) ? 0u : ld(&d.log_off[e_te < 0 ? 0 : e_te]);
+        ctrl->pmap_chunk = 0u;
         // riders are on a bus in at most CHUNK_BUS_STEPS steps of a one-pass chunk (two a day unless a lockdown froze them
         // there, Q8): that bounds the (route, bus step) pairs a wavefront of k_chunk_marks can register.  The same on all shards.
         const uint32_t bus_steps = (uint32_t)(__popcll(bus_m0) + __popcll(bus_m1));
@@ -303,6 +308,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead
         if (j == 0) {
             ctrl->vax_chunk = plan ? 1u : 0u;
             ctrl->vax_planned = plan ? n_ahead : 0u;
+            ctrl->n_neg = 0u;
             if (!sharded) ctrl->vax_fail = 0u;
             ctrl->chunk_cut = FREE_MAX + 1u;
             for (uint32_t z = FREE_MAX; z < FREE_MAX + 2u; ++z) { d.xf_adj[z] = 0u; for (uint32_t q = 0; q < 4u; ++q) d.vax_delta[q * (FREE_MAX + 2u) + z] = 0u; }
@@ -370,10 +376,11 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead
     if (tid == 0) { d.vax_cnt[j] = n_local; d.vax_now[j] = already; }
 }
 
+__device__ __forceinline__ void map_cancel(const Dev &d, Ctrl *ctrl, uint32_t c, uint32_t w, uint32_t t0, uint32_t j);
 // The Infected census ahead (buffer F) counts everybody whose exposure step makes it Infected; those the plan vaccinates
 // before leave it.  One thread per planned citizen: if its own step is the one that won, and the citizen is Infected in some
 // later step of the chunk, that stretch goes into the difference array xf_adj (k_decide adds its prefix sums to F).
-__global__ __launch_bounds__(TPB) void k_chunk_vax_adj(Dev d, uint32_t max_ahead, uint32_t limit_t)
+__global__ __launch_bounds__(TPB) void k_chunk_vax_adj(Dev d, uint32_t max_ahead, uint32_t limit_t, int pmap)
 {
     const Ctrl *ctrl = d.ctrl;
     if (!ctrl->vax_chunk || ctrl->vax_fail) return;
@@ -383,11 +390,15 @@ __global__ __launch_bounds__(TPB) void k_chunk_vax_adj(Dev d, uint32_t max_ahead
     if (j >= n_ahead) return;
     const uint32_t cnt = d.vax_cnt[j];
     for (uint32_t i = threadIdx.x; i < cnt; i += TPB) {
-        const uint32_t w = d.cit[d.vax_ev[(size_t)j * VACC_MAX_RATE + i]], te = CW_TE(w);
+        const uint32_t cz = d.vax_ev[(size_t)j * VACC_MAX_RATE + i];
+        const uint32_t w = d.cit[cz], te = CW_TE(w);
         if (CW_VAX_REL(w) != j || te >= TE_RECOVERED) continue;                // not the winning step / never exposed
         const int a = (int)te - (int)TE_BIAS + (int)d.exposed_time + 1 - (int)t0;   // Infected in steps [a, a + infected_time] of the chunk
         const int lo = a > (int)j + 1 ? a : (int)j + 1, hi = min(a + (int)d.infected_time, (int)n_ahead - 1);
         if (lo <= hi) { atomicSub(&d.xf_adj[lo], 1u); atomicAdd(&d.xf_adj[hi + 1], 1u); }
+        // persistent map: a citizen it holds already (k_map_enter handles those that turn Infected in this chunk) and whose stretch
+        // reaches beyond step j is cancelled from step j + 1 on -- to the end of its stretch, whatever the chunk's length
+        if (pmap && (w & CW_IN_MAP) && ctrl->map_t == t0 && a + (int)d.infected_time > (int)j) map_cancel(d, const_cast<Ctrl *>(ctrl), cz, w, t0, j);
     }
 }
 
@@ -560,6 +571,272 @@ __device__ __forceinline__ void schedule_masks(uint32_t lane, uint32_t n, const 
 {
     AW = M96{ __ballot(lane < n && q0.at_work != 0u), (uint32_t)__ballot(64u + lane < n && q1.at_work != 0u) };
     BUS = M96{ __ballot(lane < n && q0.bus_dir != 0u), (uint32_t)__ballot(64u + lane < n && q1.bus_dir != 0u) };
+}
+
+// ------------------------------------------------------------------------------- persistent item map
+// k_chunk_marks rebuilds the map of items from the exposure log in every chunk, and k_chunk_scatter tears it down again -- although
+// an Infected citizen stands in the same buildings for its whole stretch of infected_time + 1 steps, three to four chunks.  In the
+// persistent form an item's records are ABSOLUTE: the citizen's exposure step (from which its Infected stretch
+// follows in any chunk) instead of a stretch relative to one chunk's first step.  A citizen is entered ONCE, by the chunk in which
+// it turns Infected (k_map_enter walks the log slice of those only; CW_IN_MAP in its word), and never taken out: a record whose
+// stretch has passed contributes nothing.  A vaccination planned for an Infected citizen (k_chunk_vax) adds a CANCELLATION
+// record -- same citizen, negative, from the step after the vaccination on -- instead of searching for the record: it stays for
+// good when the step is committed and is zeroed through Dev::neg_list when it is not.  Routes are items like the others: their
+// records are their Infected riders, and the draw pass finds the bus steps with an Infected rider from them.  Everything that
+// advances the clock without maintaining the map invalidates it (Ctrl::map_t); the next chunk then starts with k_map_clear and
+// enters everybody who is Infected in it -- which is also how dead items are shed every few chunks.
+//   record: bits 0-12 exposure step + TE_BIAS | 13-25 cancellation: absent AFTER this step (absolute; only with PIV_NEG) |
+//           26 rides public transport | 27 has a work place | 28 stands in its work building / room | 29 rider record of a route |
+//           30 cancellation | 31 valid
+#define PIV_VALID   0x80000000u
+#define PIV_NEG     (1u << 30)
+#define PIV_ROUTE   (1u << 29)
+#define PIV_AS_WORK (1u << 28)
+#define PIV_HW      (1u << 27)
+#define PIV_PT      (1u << 26)
+#define PIV_CUT_SHIFT 13u
+// slot_state of a persistent slot: records appended so far | listed as an item | every record in `ovf` (a school building: its
+// rooms read its per-step counters only)
+#define PSLOT_COUNT   0x00FFFFFFu
+#define PSLOT_LISTED  0x40000000u
+#define PSLOT_ALL_OVF 0x20000000u
+struct ChunkT { int te0; int it; int t0; uint32_t n; };      // te0: the exposure step (+ TE_BIAS) that turns Infected in step 0 of the chunk
+__device__ __forceinline__ ChunkT chunk_t(const Dev &d, uint32_t t0, uint32_t n)
+{
+    return ChunkT{ (int)(t0 + TE_BIAS) - (int)d.exposed_time - 1, (int)d.infected_time, (int)t0, n };
+}
+// The steps of the chunk in which the citizen of a persistent record stands where the record was left.
+__device__ __forceinline__ M96 piv_steps(uint32_t iv, const ChunkT &ct, const M96 &AW, const M96 &BUS)
+{
+    if (!(iv & PIV_VALID)) return M96{ 0ull, 0u };
+    int a = (int)(iv & 0x1FFFu) - ct.te0;
+    const int b = min(a + ct.it, (int)ct.n - 1);
+    if (iv & PIV_NEG) a = max(a, (int)((iv >> PIV_CUT_SHIFT) & 0x1FFFu) - ct.t0 + 1);
+    a = max(a, 0);
+    if (a > b) return M96{ 0ull, 0u };
+    const M96 I = m96_range((uint32_t)a, (uint32_t)b);
+    if (iv & PIV_ROUTE) return m96_and(I, BUS);
+    const M96 rest = (iv & PIV_PT) ? m96_andn(I, BUS) : I;
+    const M96 atw = (iv & PIV_HW) ? m96_and(rest, AW) : M96{ 0ull, 0u };
+    return (iv & PIV_AS_WORK) ? atw : m96_andn(rest, atw);
+}
+__device__ __forceinline__ void piv_count(uint32_t iv, uint32_t lane, const ChunkT &ct, const M96 &AW, const M96 &BUS, uint32_t &c0, uint32_t &c1)
+{
+    const M96 at = piv_steps(iv, ct, AW, BUS);
+    const uint32_t b0 = (uint32_t)(at.lo >> lane) & 1u, b1 = lane < 32u ? (at.hi >> lane) & 1u : 0u;
+    if (iv & PIV_NEG) { c0 -= b0; c1 -= b1; } else { c0 += b0; c1 += b1; }     // (a cancellation never outruns what it cancels: sums stay >= 0)
+}
+
+
+// The map is emptied (a rebuild follows): the slots of every listed item, the spilled per-step counters, the in-map bits of
+// everybody the log holds from the earliest exposure step that can still be Infected.  Ctrl::map_t = 0xFFFFFFFF says "empty".
+__global__ __launch_bounds__(TPB) void k_map_clear(Dev d)
+{
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t tid = blockIdx.x * TPB + threadIdx.x, nth = gridDim.x * TPB;
+    const uint32_t per = d.items_cap / SUBQ;
+    for (uint32_t s = 0; s < SUBQ; ++s) {
+        const uint32_t cnt = min(d.used_cnt[s], per);
+        for (uint32_t k = tid; k < cnt; k += nth) {
+            const uint32_t v = s * per + k, h = d.hitems[v];
+            if (h >= d.hcap) continue;
+            if ((d.slot_state[h] & PSLOT_COUNT) > ITEM_RECS || (d.item_rec[v].id < d.n_bld && d.item_rec[v].aux == ESIM_SCHOOL))
+                for (uint32_t j = 0; j < FREE_MAX; ++j) d.vec[(size_t)h * FREE_MAX + j] = 0u;
+            d.hkey[h] = HKEY_EMPTY; d.slot_state[h] = 0u; d.hitems[v] = ITEM_UNUSED;
+        }
+    }
+    const int lo_te = (int)(ctrl->t + TE_BIAS) - (int)d.exposed_time - 1 - (int)d.infected_time;
+    const uint32_t i0 = d.log_off[lo_te < 0 ? 0 : lo_te], i1 = ctrl->log_len;
+    for (uint32_t i = i0 + tid; i < i1; i += nth) { const uint32_t c = d.log[i]; if (d.cit[c] & CW_IN_MAP) atomicAnd(&d.cit[c], ~CW_IN_MAP); }
+}
+__global__ __launch_bounds__(64) void k_map_reset(Dev d)
+{
+    const uint32_t lane = threadIdx.x;
+    d.used_cnt[lane] = 0u; d.pbig_cnt[lane] = 0u;
+    if (lane == 0) { d.ctrl->map_t = 0xFFFFFFFFu; d.ctrl->n_neg = 0u; }
+}
+
+// One record of a citizen into one slot of the persistent map; returns nothing the caller has to wait for.  kind 0 home building,
+// 1 work building, 2 room, 3 route; all_ovf: a school building (every record in `ovf`).  A first record in `ovf` lists the slot
+// for k_map_fold; a cancellation record notes its address in Dev::neg_list.
+__device__ __forceinline__ void map_append(const Dev &d, Ctrl *ctrl, uint32_t slot, uint32_t pos, uint32_t rec, uint32_t base2, uint32_t cap2, bool all_ovf,
+                                            uint32_t wave, uint32_t neg_step)
+{
+    uint32_t where;
+    if (!all_ovf && pos < ITEM_RECS) { where = slot * SLOT_IV_STRIDE + pos; d.slot_iv[where] = rec; }
+    else {
+        const uint32_t q = all_ovf ? pos : pos - ITEM_RECS;
+        if (q >= cap2) { ctrl->error = (uint32_t)(-ESIM_ERANGE); return; }     // (a member leaves one record and at most one cancellation per item)
+        d.ovf[base2 + q] = rec;
+        where = 0x80000000u | (base2 + q);
+        if (q == 0u) {
+            const uint32_t r = wave & (SUBQ - 1u), at = atomicAdd(&d.pbig_cnt[r], 1u);
+            if (at < d.big_qcap) { uint32_t *bl = d.big_list + ((size_t)r * d.big_qcap + at) * 3u; bl[0] = slot; bl[1] = base2; bl[2] = cap2 | (all_ovf ? 0x80000000u : 0u); }
+            else ctrl->error = (uint32_t)(-ESIM_ERANGE);
+        }
+    }
+    if (rec & PIV_NEG) {
+        const uint32_t i = atomicAdd(&ctrl->n_neg, 1u);
+        if (i < NEG_CAP) { d.neg_list[2u * i] = where; d.neg_list[2u * i + 1u] = neg_step; } else ctrl->error = (uint32_t)(-ESIM_ERANGE);
+    }
+}
+
+// Find (or, with `insert`, make) the slot of a key in the open-addressing map.  Returns ITEM_UNUSED when it is not there.
+__device__ __forceinline__ uint32_t map_slot(const Dev &d, Ctrl *ctrl, unsigned long long key, bool insert)
+{
+    uint32_t h = hash64(key) & (d.hcap - 1u);
+    for (uint32_t probe = 0; probe < d.hcap; ++probe) {
+        unsigned long long seen = d.hkey[h];
+        if (seen == HKEY_EMPTY) { if (!insert) return ITEM_UNUSED; seen = atomicCAS(&d.hkey[h], HKEY_EMPTY, key); if (seen == HKEY_EMPTY) return h; }
+        if (seen == key) return h;
+        h = (h + 1u) & (d.hcap - 1u);
+    }
+    ctrl->error = (uint32_t)(-ESIM_ERANGE);
+    return ITEM_UNUSED;
+}
+
+// Where the records of key `kind` of citizen c go beyond the slot's own: (base, capacity) of its stretch of `ovf`, two places per
+// member (a record and a cancellation).
+__device__ __forceinline__ void map_ovf_range(const Dev &d, uint32_t kind, uint32_t id, uint32_t &base2, uint32_t &cap2)
+{
+    uint32_t base, cap;
+    if (kind < 2u) { base = d.ovf_off[id]; cap = d.ovf_off[id + 1u] - base; }
+    else if (kind == 2u) { const uint32_t o = d.room_off[id]; base = d.ovf_room_base + o; cap = d.room_off[id + 1u] - o; }
+    else { const uint32_t o = d.route_off[id]; base = d.ovf_route_base + o; cap = d.route_off[id + 1u] - o; }
+    base2 = 2u * base; cap2 = 2u * cap;
+}
+
+// generate_exposures for the persistent map: one LANE per citizen that TURNS Infected in the chunk (a rebuild: per citizen that is
+// Infected in it at all).  The citizen leaves one record with each item it can ever stand in while Infected -- its home, its
+// work building and room, its route -- whatever this chunk's schedule is: the records outlive the chunk.
+__global__ __launch_bounds__(TPB) void k_map_enter(Dev d)
+{
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t t0 = ctrl->chunk_t0, n = ctrl->chunk_ok;
+    if (!ctrl->chunk_parallel || n == 0u) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
+    const uint32_t map_t = ctrl->map_t;
+    const bool rebuild = map_t != t0;
+    if (rebuild && map_t != 0xFFFFFFFFu) { if (wave == 0 && lane == 0) ctrl->error = (uint32_t)(-ESIM_ESTATE); return; }   // (the host clears before a rebuild)
+    {
+        const uint32_t q = (t0 + MARK_SLOTS - 1u) & (MARK_SLOTS - 1u);        // marks a sequential step left (see k_chunk_marks)
+        const uint32_t tid = blockIdx.x * TPB + threadIdx.x, nth = gridDim.x * TPB;
+        const uint32_t ob = ctrl->n_touched_bld[q], orr = ctrl->n_touched_room[q], ort = ctrl->n_touched_route[q], orb = ctrl->n_touched_route_big[q];
+        for (uint32_t i = tid; i < ob; i += nth) d.cnt_bld[q][d.touched_bld[q][i]] = 0u;
+        for (uint32_t i = tid; i < orr; i += nth) d.cnt_room[q][d.touched_room[q][i]] = 0u;
+        for (uint32_t i = tid; i < ort; i += nth) d.route_flag[q][d.touched_route[q][i]] = 0u;
+        for (uint32_t i = tid; i < orb; i += nth) d.route_flag[q][d.touched_route_big[q][i]] = 0u;
+    }
+    const uint32_t per = d.items_cap / SUBQ;
+    if (wave == 0 && lane == 0) { ctrl->items_per_wave = per; ctrl->n_items = per * SUBQ; ctrl->pmap_chunk = 1u; }
+    const uint32_t i0 = rebuild ? ctrl->chunk_i0 : ctrl->chunk_e0, i1 = ctrl->chunk_i1;
+    const ChunkT ct = chunk_t(d, t0, n);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t sub = wave & (SUBQ - 1u);
+    WORK_TALLY;
+    const uint32_t E = i1 - i0;
+    for (uint32_t round = 0; wave + n_waves * (round * 64u) < E; ++round) {
+        const uint32_t idx = wave + n_waves * (round * 64u + lane);
+        bool act = idx < E;
+        uint32_t c = 0u, w = 0u;
+        if (act) { c = d.log[i0 + idx]; w = d.cit[c]; }
+        const uint32_t te = CW_TE(w);
+        const int a = (int)te - ct.te0;                                        // first Infected step, relative to the chunk
+        const uint32_t vrel = CW_VAX_REL(w);
+        // not (any more) Infected in this chunk; entered already; or Vaccinated (by the chunk's plan) before it would turn Infected
+        if (te >= TE_RECOVERED || (w & CW_IN_MAP) || a > (int)n - 1 || a + ct.it < 0 || (vrel != CW_VAX_NONE && (int)vrel < a)) act = false;
+        if (act) WORK_ADD(WK_ENTRIES, 1);
+        const bool school = w & FL_WORK_SCHOOL, has_work = w & FL_HAS_WORK;
+        uint32_t id[4] = { 0u, 0u, 0u, 0u };
+        bool use[4] = { act, act && has_work, act && has_work && school, false };
+        if (act) id[0] = d.home[c];
+        if (use[1]) id[1] = d.work[c];
+        if (use[2]) { id[2] = d.room[c]; if (id[2] == 0xFFFFFFFFu) use[2] = false; }
+        if (act && (w & FL_USES_PT)) { id[3] = d.route_of[c]; use[3] = id[3] != NO_ROUTE; }
+        uint32_t slot[4] = { ITEM_UNUSED, ITEM_UNUSED, ITEM_UNUSED, ITEM_UNUSED };
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+            if (use[k]) {
+                WORK_ADD(WK_KEYS, 1);
+                slot[k] = map_slot(d, ctrl, (unsigned long long)id[k] + (k == 2u ? d.n_bld : k == 3u ? d.n_bld + d.n_room : 0u), true);
+                if (slot[k] == ITEM_UNUSED) use[k] = false;
+            }
+        // the record(s): the citizen's exposure step and what decides where it stands; a plan that vaccinates it at the end of step
+        // vrel cancels it from the step after
+        const uint32_t fl = PIV_VALID | te | ((w & FL_USES_PT) ? PIV_PT : 0u) | (has_work ? PIV_HW : 0u);
+        const bool neg = act && vrel != CW_VAX_NONE && (int)vrel < a + ct.it;   // (to the end of its stretch, whatever the chunk's length)
+        const uint32_t cut = neg ? ((t0 + vrel) << PIV_CUT_SHIFT) | PIV_NEG : 0u;
+        uint32_t old[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) if (use[k]) old[k] = atomicAdd(&d.slot_state[slot[k]], neg ? 2u : 1u);
+        // whoever finds a slot that is not listed as an item lists it: the next ids of this wavefront's sub-list
+        bool lists[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            lists[k] = false;
+            if (use[k] && !(old[k] & PSLOT_LISTED)) lists[k] = !(atomicOr(&d.slot_state[slot[k]], PSLOT_LISTED) & PSLOT_LISTED);
+        }
+        uint32_t before = 0u, n_claims = 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) { const unsigned long long cm = __ballot(lists[k]); before += (uint32_t)__popcll(cm & lt); n_claims += (uint32_t)__popcll(cm); }
+        uint32_t first_id = 0u;
+        if (n_claims) {
+            if (lane == 0) first_id = atomicAdd(&d.used_cnt[sub], n_claims);
+            first_id = FX(first_id, 0);
+            if (first_id + n_claims > per) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); n_claims = 0u; }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            if (lists[k] && n_claims) {
+                WORK_ADD(WK_CLAIMS, 1);
+                const uint32_t v = sub * per + first_id + before++;
+                d.hitems[v] = slot[k];
+                ItemRec rec = { id[k] + (k == 2u ? d.n_bld : k == 3u ? d.n_bld + d.n_room : 0u), 0u, 0u, 0u, 0u, 0u, k == 2u ? slot[1] : 0xFFFFFFFFu, 0u };
+                if (k < 2u) {
+                    rec.a_lo = d.res_off[id[k]]; rec.a_hi = d.res_off[id[k] + 1u];
+                    rec.b_lo = d.wrk_off[id[k]]; rec.b_hi = d.wrk_off[id[k] + 1u];
+                    rec.aux = (uint32_t)d.bld_type[id[k]];
+                } else if (k == 2u) { rec.a_lo = d.room_off[id[2]]; rec.a_hi = d.room_off[id[2] + 1u]; rec.aux = d.room_bld[id[2]]; }
+                else { rec.a_lo = d.route_off[id[3]]; rec.a_hi = d.route_off[id[3] + 1u]; }
+                d.item_rec[v] = rec;
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            if (!use[k]) continue;
+            WORK_ADD(WK_RECORDS, 1);
+            uint32_t base2, cap2;
+            map_ovf_range(d, k, id[k], base2, cap2);
+            const uint32_t rec = fl | (k == 3u ? PIV_ROUTE : (k == 0u ? 0u : PIV_AS_WORK));
+            const bool all_ovf = k == 1u && school;
+            const uint32_t pos = old[k] & PSLOT_COUNT;
+            map_append(d, ctrl, slot[k], pos, rec, base2, cap2, all_ovf, wave, 0u);
+            if (neg) map_append(d, ctrl, slot[k], pos + 1u, rec | cut, base2, cap2, all_ovf, wave, vrel);
+        }
+        if (act) atomicOr(&d.cit[c], CW_IN_MAP);
+    }
+    WORK_FLUSH(d);
+}
+
+// A vaccination planned for the end of step j of the chunk, of a citizen whose records the map holds already: a cancellation record
+// from step j + 1 on with each of its items (k_chunk_vax_adj calls this for the citizens whose own step won).
+__device__ __forceinline__ void map_cancel(const Dev &d, Ctrl *ctrl, uint32_t c, uint32_t w, uint32_t t0, uint32_t j)
+{
+    const uint32_t te = CW_TE(w);
+    const bool school = w & FL_WORK_SCHOOL, has_work = w & FL_HAS_WORK;
+    const uint32_t fl = PIV_VALID | PIV_NEG | ((t0 + j) << PIV_CUT_SHIFT) | te | ((w & FL_USES_PT) ? PIV_PT : 0u) | (has_work ? PIV_HW : 0u);
+    uint32_t id[4] = { d.home[c], has_work ? d.work[c] : 0u, (has_work && school) ? d.room[c] : 0xFFFFFFFFu, (w & FL_USES_PT) ? d.route_of[c] : NO_ROUTE };
+    const bool use[4] = { true, has_work, has_work && school && id[2] != 0xFFFFFFFFu, id[3] != NO_ROUTE };
+    for (uint32_t k = 0; k < 4u; ++k) {
+        if (!use[k]) continue;
+        const uint32_t slot = map_slot(d, ctrl, (unsigned long long)id[k] + (k == 2u ? d.n_bld : k == 3u ? d.n_bld + d.n_room : 0u), false);
+        if (slot == ITEM_UNUSED) { ctrl->error = (uint32_t)(-ESIM_ESTATE); continue; }     // (its record is there: CW_IN_MAP)
+        uint32_t base2, cap2;
+        map_ovf_range(d, k, id[k], base2, cap2);
+        const uint32_t pos = atomicAdd(&d.slot_state[slot], 1u) & PSLOT_COUNT;
+        map_append(d, ctrl, slot, pos, fl | (k == 3u ? PIV_ROUTE : (k == 0u ? 0u : PIV_AS_WORK)), base2, cap2, k == 1u && school, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, j);
+    }
 }
 
 // generate_exposures (simulator.rs:181-198) for every step of the chunk: one LANE per citizen that is Infected somewhere in
@@ -857,6 +1134,9 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
 // The interval records k_chunk_marks put into `ovf` (slots with more than ITEM_RECS of them: schools, large work places),
 // summed into the slots' per-step counters before the draw pass reads them.  One wavefront per listed slot, 64 records at a
 // time; each lane turns its record into the set of steps in which that citizen stands there, one ballot per step counts them.
+// PM: the persistent map -- the listed slots are those of Dev::pbig_cnt (they stay listed), their records are absolute, the
+// sums are STORED (nobody else adds to them), and the prefix sums are those of the SUBQ sub-lists the item ids are handed out from.
+template <bool PM>
 __global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
 {
     Ctrl *ctrl = d.ctrl;
@@ -865,18 +1145,19 @@ __global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
     const uint32_t per_wave = ld(&ctrl->items_per_wave);
-    if ((unsigned long long)per_wave * n_waves > d.items_cap) return;
+    const uint32_t n_own = PM ? SUBQ : n_waves;                              // owners of item id ranges
+    if ((unsigned long long)per_wave * n_own > d.items_cap) return;
     if (blockIdx.x == 0) {
         // for k_chunk_draw: used_pref[k] = ids handed out by the wavefronts before k
         __shared__ uint32_t s_pref[CHUNK_WAVES_MAX + 1u];
         __shared__ uint32_t s_wtot[TPB / 64];
         const uint32_t pf0 = PROF_NOW();
         constexpr uint32_t RUN = CHUNK_WAVES_MAX / TPB;
-        const uint32_t run = (n_waves + TPB - 1u) / TPB, b = threadIdx.x * run;   // <= RUN
+        const uint32_t run = (n_own + TPB - 1u) / TPB, b = threadIdx.x * run;   // <= RUN
         uint32_t cnt[RUN];
         uint32_t sum = 0u;
 #pragma unroll
-        for (uint32_t k = 0; k < RUN; ++k) { cnt[k] = (k < run && b + k < n_waves) ? min(d.used_cnt[b + k], per_wave) : 0u; sum += cnt[k]; }
+        for (uint32_t k = 0; k < RUN; ++k) { cnt[k] = (k < run && b + k < n_own) ? min(d.used_cnt[b + k], per_wave) : 0u; sum += cnt[k]; }
         uint32_t x = sum;
         for (uint32_t o = 1; o < 64u; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
         if (lane == 63u) s_wtot[threadIdx.x >> 6] = x;
@@ -886,16 +1167,17 @@ __global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
         uint32_t acc = x - sum;
         for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) acc += s_wtot[k];
 #pragma unroll
-        for (uint32_t k = 0; k < RUN; ++k) if (k < run && b + k < n_waves) { acc += cnt[k]; s_pref[b + k + 1u] = acc; }
+        for (uint32_t k = 0; k < RUN; ++k) if (k < run && b + k < n_own) { acc += cnt[k]; s_pref[b + k + 1u] = acc; }
         __syncthreads();
         const uint32_t pf2 = PROF_NOW();
-        for (uint32_t w = threadIdx.x; w <= n_waves; w += TPB) d.used_pref[w] = s_pref[w];
+        for (uint32_t w = threadIdx.x; w <= n_own; w += TPB) d.used_pref[w] = s_pref[w];
         BOOKS_PROF(d, 8, pf1 - pf0); BOOKS_PROF(d, 9, pf2 - pf1); BOOKS_PROF(d, 10, PROF_NOW() - pf2);
         (void)pf0; (void)pf1; (void)pf2;
     }
     // list `wave & 63`, every (n_waves / 64)-th entry of it
     const uint32_t qr = wave & (SUBQ - 1u), first = wave >> 6, step = n_waves >> 6;
-    const uint32_t n_list = step ? min(ld(&d.hot[(HOT_BIG + qr) * HOT_STRIDE]), d.big_qcap) : 0u;
+    const uint32_t n_list = step ? min(PM ? d.pbig_cnt[qr] : ld(&d.hot[(HOT_BIG + qr) * HOT_STRIDE]), d.big_qcap) : 0u;
+    const ChunkT ct = chunk_t(d, ctrl->chunk_t0, n);
 #ifdef ESIM_PROFILE_FOLD
     const uint32_t pq0 = PROF_NOW();
     uint32_t pq_rec = 0u, pq_n = 0u;
@@ -915,10 +1197,11 @@ __global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
         const uint32_t mine = g + lane * step;
         if (mine < n_list) {
             slot_l = bl[3u * mine]; base_l = bl[3u * mine + 1u];
-            const uint32_t cap_l = bl[3u * mine + 2u];
+            const uint32_t cap_l = bl[3u * mine + 2u] & 0x7FFFFFFFu, all_ovf = bl[3u * mine + 2u] >> 31;   // (bit 31: a school building of the persistent map)
             if (slot_l < d.hcap && base_l <= d.ovf_n && cap_l <= d.ovf_n - base_l) {
                 const uint32_t state = d.slot_state[slot_l];
-                n_ov_l = min((state > ITEM_RECS && state < SLOT_COUNTERS_ONLY) ? state - ITEM_RECS : 0u, cap_l);
+                if (PM) { const uint32_t cnt = state & PSLOT_COUNT, inl = all_ovf ? 0u : ITEM_RECS; n_ov_l = min(cnt > inl ? cnt - inl : 0u, cap_l); }
+                else n_ov_l = min((state > ITEM_RECS && state < SLOT_COUNTERS_ONLY) ? state - ITEM_RECS : 0u, cap_l);
             } else { slot_l = 0u; base_l = 0u; ctrl->error = (uint32_t)(-ESIM_ERANGE); }   // (no list entry k_chunk_marks wrote looks like this)
         }
         const uint32_t m = min(64u, (n_list - g + step - 1u) / step);
@@ -944,18 +1227,36 @@ __global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
                 if (nb <= 12u) {
                     // few records (a class room): one after the other, its set of steps in scalar registers, lanes = steps
                     for (uint32_t k = 0; k < nb; ++k) {
+                        if (PM) { piv_count(FX(iv, k), lane, ct, AW, BUS, c0, c1); continue; }
                         const M96 at = iv_steps(FX(iv, k), AW, BUS);
                         c0 += (uint32_t)(at.lo >> lane) & 1u;
                         c1 += lane < 32u ? (at.hi >> lane) & 1u : 0u;
                     }
                     continue;
                 }
-                // many: lanes = records, one ballot per step
-                const M96 at = iv_steps(iv, AW, BUS);
-                for (uint32_t j = 0; j < n && j < 64u; ++j) { const uint32_t k = (uint32_t)__popcll(__ballot((at.lo >> j) & 1ull)); if (lane == j) c0 += k; }
-                for (uint32_t j = 64u; j < n; ++j) { const uint32_t k = (uint32_t)__popcll(__ballot((at.hi >> (j - 64u)) & 1u)); if (lane == j - 64u) c1 += k; }
+                // many: lanes = records, one ballot per step (persistent map: cancellation records count negative)
+                const M96 at = PM ? piv_steps(iv, ct, AW, BUS) : iv_steps(iv, AW, BUS);
+                const bool negr = PM && (iv & PIV_NEG);
+                const bool any_neg = PM && __any(negr);
+                for (uint32_t j = 0; j < n && j < 64u; ++j) {
+                    const bool here = (at.lo >> j) & 1ull;
+                    uint32_t k = (uint32_t)__popcll(__ballot(here && !negr));
+                    if (any_neg) k -= (uint32_t)__popcll(__ballot(here && negr));
+                    if (lane == j) c0 += k;
+                }
+                for (uint32_t j = 64u; j < n; ++j) {
+                    const bool here = (at.hi >> (j - 64u)) & 1u;
+                    uint32_t k = (uint32_t)__popcll(__ballot(here && !negr));
+                    if (any_neg) k -= (uint32_t)__popcll(__ballot(here && negr));
+                    if (lane == j - 64u) c1 += k;
+                }
             }
             uint32_t *v = d.vec + (size_t)slot * FREE_MAX;
+            if (PM) {                                                         // (the map's counters belong to this kernel alone)
+                if (lane < n) v[lane] = c0;
+                if (64u + lane < n) v[64u + lane] = c1;
+                continue;
+            }
             // (added, not stored: commuters from other shards may have counted themselves there; atomics, because nobody has
             // to wait for them)
             if (lane < n && c0) atomicAdd(&v[lane], c0);
@@ -1137,6 +1438,8 @@ __device__ __forceinline__ uint32_t item_steps_regs(uint32_t c0, uint32_t c1, ui
 __device__ __forceinline__ uint32_t fetch_slot(const Dev &d, uint32_t slot, uint32_t lane);
 __device__ __forceinline__ void item_counts(const Dev &d, uint32_t x, uint32_t slot, uint32_t lane, uint32_t n, const M96 &AW,
                                             const M96 &BUS, uint32_t &c0, uint32_t &c1);
+__device__ __forceinline__ void pitem_counts(const Dev &d, uint32_t x, uint32_t slot, uint32_t lane, const ChunkT &ct, const M96 &AW,
+                                             const M96 &BUS, bool vec_only, uint32_t &c0, uint32_t &c1);
 __device__ __forceinline__ void school_counts(const Dev &d, uint32_t s_sch, uint32_t lane, uint32_t n, const Decision &q0, const Decision &q1, WaveScratch &ws)
 {
     // s_sch: the hash slot of the room's school (k_chunk_marks left it in the room's record): infected in the whole school, per
@@ -1226,14 +1529,34 @@ __device__ __forceinline__ void item_counts(const Dev &d, uint32_t x, uint32_t s
     }
 }
 
-__device__ __forceinline__ ItemFetch decode_item(const Dev &d, uint32_t x, uint32_t lane, uint32_t n, const M96 &AW, const M96 &BUS)
+// The same for a slot of the persistent map: its records are absolute (piv_count); beyond ITEM_RECS of them (or all of them:
+// vec_only, a school building) k_map_fold has left the sums in `vec`.
+__device__ __forceinline__ void pitem_counts(const Dev &d, uint32_t x, uint32_t slot, uint32_t lane, const ChunkT &ct, const M96 &AW,
+                                             const M96 &BUS, bool vec_only, uint32_t &c0, uint32_t &c1)
+{
+    const uint32_t cnt = FX(x, LANE_STATE) & PSLOT_COUNT;
+    c0 = 0u; c1 = 0u;
+    if (vec_only ? cnt > 0u : cnt > ITEM_RECS) {
+        if (lane < ct.n) c0 = d.vec[(size_t)slot * FREE_MAX + lane];
+        if (64u + lane < ct.n) c1 = d.vec[(size_t)slot * FREE_MAX + 64u + lane];
+    }
+    if (vec_only) return;
+    const uint32_t n_rec = cnt < ITEM_RECS ? cnt : ITEM_RECS;
+    for (uint32_t k = 0; k < n_rec; ++k) piv_count(FX(x, 8u + k), lane, ct, AW, BUS, c0, c1);
+}
+
+template <bool PM>
+__device__ __forceinline__ ItemFetch decode_item(const Dev &d, uint32_t x, uint32_t lane, uint32_t n, const ChunkT &ct, const M96 &AW, const M96 &BUS)
 {
     ItemFetch f;
     f.slot = FX(x, LANE_HSLOT); f.id = FX(x, 0); f.a_lo = FX(x, 1); f.a_hi = FX(x, 2); f.b_lo = FX(x, 3); f.b_hi = FX(x, 4); f.aux = FX(x, 5); f.link = FX(x, 6);
     f.c0 = 0u; f.c1 = 0u;
     if (f.slot < d.hcap) {
-        item_counts(d, x, f.slot, lane, n, AW, BUS, f.c0, f.c1);
-        iv_count(FX(x, 7), lane, AW, BUS, f.c0, f.c1);
+        if (PM) pitem_counts(d, x, f.slot, lane, ct, AW, BUS, false, f.c0, f.c1);
+        else {
+            item_counts(d, x, f.slot, lane, n, AW, BUS, f.c0, f.c1);
+            iv_count(FX(x, 7), lane, AW, BUS, f.c0, f.c1);
+        }
     }
     return f;
 }
@@ -1249,6 +1572,49 @@ __device__ __forceinline__ bool item_ok(const Dev &d, const ItemFetch &it)
 }
 #define PAIR_SPREAD 1237u
 // apply_exposures (simulator.rs:262-405) for every item and every step of the chunk.
+// One (route of <= 64 riders, bus step j) pair with an Infected rider: rank the riders by (Philox key, id) with shuffles, buses
+// are runs of bus_capacity ranks, every bus with an Infected rider draws for its Susceptible riders (simulator.rs:362-401).
+__device__ __forceinline__ void route_pair_small(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, uint32_t off, uint32_t sz, uint32_t j, uint32_t t0, uint32_t lane WORK_ARG)
+{
+    const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
+    const uint32_t s = t0 + j, mask = sm.dec[j].mask;
+    uint32_t c = 0, w = 0, key = 0;
+    bool inf = false;
+    WORK_ADD(WK_ROUTE_PAIRS, lane == 0 ? 1 : 0); WORK_ADD(WK_RIDERS, lane < sz ? 1 : 0);
+    if (lane < sz) {
+        c = d.route_riders[off + lane];
+        w = d.cit[c];
+        inf = status_in_chunk(d, w, t0, j) == ESIM_INFECTED;
+        key = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
+    }
+    uint32_t rank = 0;
+    for (uint32_t i = 0; i < sz; ++i) {
+        const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)i);   // i is uniform: a scalar broadcast
+        rank += ki < key || (ki == key && i < lane);                     // ids ascend with the lane
+    }
+    const uint32_t bus = rank / d.bus_capacity;
+    // Infected riders on my bus: one ballot per bus of the route
+    const unsigned long long inf_m = __ballot(inf);
+    uint32_t k = 0;
+    const uint32_t n_bus = (sz + d.bus_capacity - 1u) / d.bus_capacity;
+    for (uint32_t b = 0; b < n_bus; ++b) {
+        const unsigned long long on_b = __ballot(lane < sz && bus == b);
+        if (bus == b) k = (uint32_t)__popcll(on_b & inf_m);
+    }
+    if (lane < sz && k) {
+        const uint32_t te = CW_TE(w);
+        if (!(w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_KEEP)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) || j > CW_VAX_REL(w))) {   // not exposed before this bus, not Vaccinated by then
+            const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
+            WORK_ADD(WK_BUS_DRAWS, 1);
+            if (esim_u32(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) { WORK_ADD(WK_HITS, 1); expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED); }
+        }
+    }
+}
+
+// PM: the items are those of the persistent map -- ids handed out from SUBQ sub-lists (n_mw = SUBQ), counts from absolute records,
+// routes are items among the others (their records are their Infected riders: the bus steps with any are ranked right here, longer
+// routes go to k_chunk_units' list), and there is no list of (route, step) pairs.
+template <bool PM>
 __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
 {
     __shared__ ChunkShared sm;
@@ -1310,7 +1676,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
     const uint32_t w_base = wave % n_mw, w_rep = wave / n_mw;
     uint32_t code_l = 0u, off_l = 0u, sz_l = 0u;
     bool have = false;
-    {
+    if (!PM) {
         const uint32_t k = lane * G + w_rep;
         if (k < K) {
             const uint32_t src = (w_base + n_mw - (uint32_t)(((unsigned long long)k * PAIR_SPREAD) % n_mw)) % n_mw;
@@ -1328,6 +1694,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
     M96 AW, BUS;
     schedule_masks(lane, n, q0, q1, AW, BUS);
     const M96 EV = { __ballot(lane < n && q0.mask == ESIM_MASK_EVERYWHERE), (uint32_t)__ballot(64u + lane < n && q1.mask == ESIM_MASK_EVERYWHERE) };
+    const ChunkT ct = chunk_t(d, t0, n);
     if (d_lo < d_hi) sl_cur = fetch_slot(d, FX(id_cur, LANE_HSLOT), lane);
     if (have) { const uint32_t r = code_l >> 7; off_l = d.route_off[r]; sz_l = d.route_off[r + 1] - off_l; }
 #ifdef ESIM_WAVE_PROFILE
@@ -1342,10 +1709,35 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
         if (v + 2u < d_hi) id_nxt = fetch_item(d, id_of(v + 2u), lane);
         if (v + 1u < d_hi) sl_cur = fetch_slot(d, FX(id_cur, LANE_HSLOT), lane);
         const uint32_t pq0 = PROF_NOW();
-        const ItemFetch it = decode_item(d, x, lane, n, AW, BUS);
+        const ItemFetch it = decode_item<PM>(d, x, lane, n, ct, AW, BUS);
         if (it.slot == ITEM_UNUSED) continue;
         if (!item_ok(d, it)) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); continue; }
-        if (it.id >= route_base) continue;
+        // (persistent map: an item whose records all lie outside the chunk -- recovered, or at home under a lockdown -- is left
+        // here, before any member is fetched)
+        if (PM && !__any((it.c0 | it.c1) != 0u)) continue;
+        if (it.id >= route_base) {
+            if (PM) {
+                // the bus steps in which an Infected rider of this route is on the bus: c0 / c1 count them per step
+                const uint32_t r = it.id - route_base, sz = it.a_hi - it.a_lo;
+                if (r >= d.n_routes || it.a_hi < it.a_lo || it.a_hi > d.n_pt) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); continue; }
+                const unsigned long long m_lo = __ballot(it.c0 != 0u) & BUS.lo;
+                const uint32_t m_hi = (uint32_t)__ballot(lane < FREE_MAX - 64u && it.c1 != 0u) & BUS.hi;
+                if (sz <= 64u) {
+                    for (unsigned long long m = m_lo; m; m &= m - 1ull) route_pair_small(d, ctrl, sm, it.a_lo, sz, (uint32_t)__builtin_ctzll(m), t0, lane WORK_PASS);
+                    for (uint32_t m = m_hi; m; m &= m - 1u) route_pair_small(d, ctrl, sm, it.a_lo, sz, 64u + (uint32_t)__builtin_ctz(m), t0, lane WORK_PASS);
+                } else {
+                    const uint32_t np = (uint32_t)__popcll(m_lo) + (uint32_t)__popc(m_hi);
+                    uint32_t at = 0u;
+                    if (lane == 0) at = atomicAdd(&d.hot[HOT_BIGPAIRS * HOT_STRIDE], np);
+                    at = FX(at, 0);
+                    if (at + np > 2u * d.items_cap) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); continue; }
+                    uint32_t i = 0u;
+                    for (unsigned long long m = m_lo; m; m &= m - 1ull, ++i) if (lane == 0) d.route_pairs_big[at + i] = (r << 7) | (uint32_t)__builtin_ctzll(m);
+                    for (uint32_t m = m_hi; m; m &= m - 1u, ++i) if (lane == 0) d.route_pairs_big[at + i] = (r << 7) | (64u + (uint32_t)__builtin_ctz(m));
+                }
+            }
+            continue;
+        }
         const uint32_t pi0 = PROF_NOW();
         pst[0] += pi0 - pq0;
         (void)pi0; ++p_items; WORK_ADD(WK_ITEMS, lane == 0 ? 1 : 0);
@@ -1385,11 +1777,9 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
         { const uint32_t dt = PROF_NOW() - pi0; p_item_max = dt > p_item_max ? dt : p_item_max; }
     }
     const uint32_t pt2 = PROF_NOW();
-    // (2) routes of <= 64 riders: one wavefront per (route, bus step) with an Infected rider; rank by (Philox key, id)
-    // with shuffles, buses are runs of bus_capacity ranks (simulator.rs:362-388)
-    const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
-    // (the pairs dealt to this wavefront -- see the first look above --, taken one by one)
-    for (uint32_t k0 = 0; k0 * G < K; k0 += 64u) {
+    // (2) routes of <= 64 riders: one wavefront per (route, bus step) with an Infected rider (the pairs dealt to this wavefront --
+    // see the first look above --, taken one by one)
+    for (uint32_t k0 = 0; !PM && k0 * G < K; k0 += 64u) {
         if (k0) {                                                             // (beyond the 64 looked at up front: many Infected)
             const uint32_t kk = (k0 + lane) * G + w_rep;
             have = false;
@@ -1402,42 +1792,10 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
         }
         unsigned long long todo = __ballot(have);
         while (todo) {
-        const int src_lane = __ffsll((long long)todo) - 1;
-        todo &= todo - 1ull;
-        const uint32_t code = __shfl(code_l, src_lane, 64), off = __shfl(off_l, src_lane, 64), sz = __shfl(sz_l, src_lane, 64);
-        const uint32_t j = code & 127u;
-        const uint32_t s = t0 + j, mask = sm.dec[j].mask;
-        uint32_t c = 0, w = 0, key = 0;
-        bool inf = false;
-        WORK_ADD(WK_ROUTE_PAIRS, lane == 0 ? 1 : 0); WORK_ADD(WK_RIDERS, lane < sz ? 1 : 0);
-        if (lane < sz) {
-            c = d.route_riders[off + lane];
-            w = d.cit[c];
-            inf = status_in_chunk(d, w, t0, j) == ESIM_INFECTED;
-            key = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
-        }
-        uint32_t rank = 0;
-        for (uint32_t i = 0; i < sz; ++i) {
-            const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)i);   // i is uniform: a scalar broadcast
-            rank += ki < key || (ki == key && i < lane);                     // ids ascend with the lane
-        }
-        const uint32_t bus = rank / d.bus_capacity;
-        // Infected riders on my bus: one ballot per bus of the route
-        const unsigned long long inf_m = __ballot(inf);
-        uint32_t k = 0;
-        const uint32_t n_bus = (sz + d.bus_capacity - 1u) / d.bus_capacity;
-        for (uint32_t b = 0; b < n_bus; ++b) {
-            const unsigned long long on_b = __ballot(lane < sz && bus == b);
-            if (bus == b) k = (uint32_t)__popcll(on_b & inf_m);
-        }
-        if (lane < sz && k) {
-            const uint32_t te = CW_TE(w);
-            if (!(w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_KEEP)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) || j > CW_VAX_REL(w))) {   // not exposed before this bus, not Vaccinated by then
-                const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
-                WORK_ADD(WK_BUS_DRAWS, 1);
-                if (esim_u32(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) { WORK_ADD(WK_HITS, 1); expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED); }
-            }
-        }
+            const int src_lane = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const uint32_t code = __shfl(code_l, src_lane, 64), off = __shfl(off_l, src_lane, 64), sz = __shfl(sz_l, src_lane, 64);
+            route_pair_small(d, ctrl, sm, off, sz, code & 127u, t0, lane WORK_PASS);
         }
     }
     WORK_FLUSH(d);
@@ -1453,6 +1811,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
 
 // The deferred units of long member lists, dealt to the wavefronts round-robin.
 // Then the routes of more than 64 riders: one workgroup per (route, bus step), ranks through LDS.
+template <bool PM>
 __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
 {
     __shared__ ChunkShared sm;
@@ -1481,6 +1840,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
     M96 AW, BUS;
     schedule_masks(lane, n, q0, q1, AW, BUS);
     const M96 EV = { __ballot(lane < n && q0.mask == ESIM_MASK_EVERYWHERE), (uint32_t)__ballot(64u + lane < n && q1.mask == ESIM_MASK_EVERYWHERE) };
+    const ChunkT ct = chunk_t(d, t0, n);
     // Per unit: its record (lanes 0..7 of one register); then, together, the slot's interval records, the school's, and the
     // ids of the first members its pairs touch; then those members' words.  The record of the unit after next and the
     // second stage of the next are in flight while this one draws.
@@ -1512,11 +1872,11 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
         const uint32_t kind = code >> 30, p_lo = code & 0x3FFFFFFFu, slot = FX(u, 0), link = FX(u, 1), lo = FX(u, 2), n_mem = FX(u, 3), own = FX(u, 5), mf = FX(u, 6);
         const uint32_t mw = (mf + lane < n_mem) ? d.cit[mid] : 0u;
         uint32_t c0, c1;
-        item_counts(d, xs, slot, lane, n, AW, BUS, c0, c1);
-        iv_count(own, lane, AW, BUS, c0, c1);
+        if (PM) pitem_counts(d, xs, slot, lane, ct, AW, BUS, false, c0, c1);
+        else { item_counts(d, xs, slot, lane, n, AW, BUS, c0, c1); iv_count(own, lane, AW, BUS, c0, c1); }
         if (kind == 2u) {
             uint32_t s0 = 0u, s1 = 0u;
-            if (link != 0xFFFFFFFFu) item_counts(d, ys, link, lane, n, AW, BUS, s0, s1);
+            if (link != 0xFFFFFFFFu) { if (PM) pitem_counts(d, ys, link, lane, ct, AW, BUS, true, s0, s1); else item_counts(d, ys, link, lane, n, AW, BUS, s0, s1); }
             ws.sch[lane] = s0;
             if (lane < FREE_MAX - 64u) ws.sch[64u + lane] = s1;
         }
@@ -1660,6 +2020,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_scatter(Dev d)
     }
     // the hash slots (and spilled count vectors) of the ids that were handed out: a thread per (wavefront of k_chunk_marks,
     // k-th id of its range), so that the whole clean-up is three dependent loads deep
+    if (ctrl->prev_pmap) return;                                              // (the persistent map stays)
     const uint32_t per_wave = ctrl->prev_per_wave, n_mw = per_wave ? n_items / per_wave : 0u;
     const uint32_t tid = blockIdx.x * TPB + threadIdx.x, nth = gridDim.x * TPB;
     for (uint32_t i = tid; i < n_mw * per_wave; i += nth) {
@@ -1683,6 +2044,16 @@ __global__ __launch_bounds__(TPB) void k_chunk_vax_final(Dev d)
     Ctrl *ctrl = d.ctrl;
     if (!ctrl->prev_vax) return;
     const uint32_t n_eff = ctrl->prev_n_eff;
+    // persistent map: the cancellation records of steps that were not committed are taken back (zeroed where they stand); those of
+    // committed steps stay for good.  (n_neg is reset by the plan kernel of the next chunk: other workgroups still read it here.)
+    {
+        const uint32_t n_neg = min(ctrl->n_neg, NEG_CAP);
+        for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_neg; i += gridDim.x * TPB) {
+            const uint32_t where = d.neg_list[2u * i], j = d.neg_list[2u * i + 1u];
+            if (j < n_eff) continue;
+            if (where & 0x80000000u) d.ovf[where & 0x7FFFFFFFu] = 0u; else d.slot_iv[where] = 0u;
+        }
+    }
     // (the plan may reach beyond the chunk: the decisions can end a chunk early, k_decide)
     const uint32_t n = ctrl->prev_planned;
     for (uint32_t j = blockIdx.x; j < n; j += gridDim.x) {
@@ -1892,11 +2263,11 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
     if (!fused) {
         // k_chunk_scatter runs after this kernel, i.e. after the next chunk's decisions have reset what it reads: keep a copy
         if (tid < SUBQ) d.hot[(HOT_PREV_NEWEXP + tid) * HOT_STRIDE] = n_new;   // (thread r < 64 read sub-list r's length above)
-        if (tid == 0) { ctrl->prev_t0 = t0; ctrl->prev_n_items = n_items; ctrl->prev_per_wave = ld(&ctrl->items_per_wave);
+        if (tid == 0) { ctrl->prev_t0 = t0; ctrl->prev_n_items = n_items; ctrl->prev_per_wave = ld(&ctrl->items_per_wave); ctrl->prev_pmap = ld(&ctrl->pmap_chunk);
                         ctrl->prev_n = n; ctrl->prev_n_eff = n_eff; ctrl->prev_vax = vax ? 1u : 0u; ctrl->prev_planned = ld(&ctrl->vax_planned); ctrl->vax_chunk = 0u; }
         // (its per-step write cursors were set above, a row per EXP_ROWS-th workgroup)
     }
-    if (tid == 0) ctrl->chunk_done = 1u;
+    if (tid == 0) { ctrl->chunk_done = 1u; if (ld(&ctrl->pmap_chunk)) ctrl->map_t = t0 + n_eff; }   // the map now stands at the step the next chunk starts with
     if (tid < 64u) {
         // totals of the split lists, for esim_debug_counters
         uint32_t a = ld(&d.hot[(HOT_NEWEXP + tid) * HOT_STRIDE]), b = ld(&d.hot[(HOT_UNITS + tid) * HOT_STRIDE]);
@@ -1913,7 +2284,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
         }
         // the ids each wavefront of k_chunk_marks handed out: thread t looks after the wavefronts t, t + 1024, ...; all loads
         // of a round are in flight together (this loop is nothing but memory latency)
-        const uint32_t per_wave = ld(&ctrl->items_per_wave), n_mw = per_wave ? n_items / per_wave : 0u;
+        const uint32_t per_wave = ld(&ctrl->items_per_wave), n_mw = (per_wave && !ld(&ctrl->pmap_chunk)) ? n_items / per_wave : 0u;   // (the persistent map stays)
         for (uint32_t w0 = tid; w0 < n_mw; w0 += 4u * FIN_TPB) {
             uint32_t used[4], h[4][4];
 #pragma unroll

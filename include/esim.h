@@ -218,7 +218,7 @@ int  esim_chunk_timing(esim_ctx *ctx, double *total_ms, uint64_t *steps, uint64_
  * "Generate Exposures" = marks + fold, "Apply Exposures" = draw + units, "Apply Interventions" = everything else (plan,
  * decisions, counts, books, scatter) -- apportioned: a chunk pass works on up to 96 steps at once. */
 enum { ESIM_CK_MARKS = 0, ESIM_CK_FOLD, ESIM_CK_DRAW, ESIM_CK_UNITS, ESIM_CK_COUNT, ESIM_CK_BOOKS, ESIM_CK_SCATTER, ESIM_CK_VAX, ESIM_CK_VAX_ADJ,
-       ESIM_CK_VAX_FINAL, ESIM_CK_DECIDE, ESIM_CK_FUTURE, ESIM_CK_N };
+       ESIM_CK_VAX_FINAL, ESIM_CK_DECIDE, ESIM_CK_FUTURE, ESIM_CK_MAP_CLEAR, ESIM_CK_N };
 int  esim_enable_chunk_kernel_timing(esim_ctx *ctx, int enable);
 int  esim_chunk_kernel_timings(esim_ctx *ctx, double ms[ESIM_CK_N], uint64_t calls[ESIM_CK_N]);
 /* Steps run as time-parallel chunks under a vaccination programme (pipeline level 3: the chunk's vaccinations are planned

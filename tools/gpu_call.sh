@@ -23,6 +23,9 @@ for step in $steps; do
             echo -n "york grid 1024: "; timeout -k 10 300 python tools/run_preset.py york | grep us/step | cut -c1-140
             echo -n "york grid 64:   "; ESIM_GRID_CHUNK=64 timeout -k 10 300 python tools/run_preset.py york | grep us/step | cut -c1-140
             echo -n "york grid 16:   "; ESIM_GRID_CHUNK=16 timeout -k 10 300 python tools/run_preset.py york | grep us/step | cut -c1-140 ;;
+    pmap) ESIM_PMAP_REBUILD=1 timeout -k 10 300 python tools/fuzz_parity.py 2000 40 > gpurun_out/fuzz_pm1_$tag.log 2>&1; rc=$?; tail -3 gpurun_out/fuzz_pm1_$tag.log; [ $rc -eq 0 ] || exit $rc
+          timeout -k 10 300 python tools/fuzz_parity.py 2000 40 > gpurun_out/fuzz_pm4_$tag.log 2>&1; rc=$?; tail -3 gpurun_out/fuzz_pm4_$tag.log; [ $rc -eq 0 ] || exit $rc
+          ESIM_PMAP_REBUILD=1000 timeout -k 10 300 python tools/fuzz_parity.py 3000 40 > gpurun_out/fuzz_pmx_$tag.log 2>&1; rc=$?; tail -3 gpurun_out/fuzz_pmx_$tag.log; [ $rc -eq 0 ] || exit $rc ;;
     *) echo "unknown step $step"; exit 9 ;;
   esac
 done
