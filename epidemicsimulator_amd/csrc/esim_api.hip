@@ -433,8 +433,12 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         HIP_TRY(c, hipMemset(d.route_pairs, 0, sizeof(uint32_t) * (size_t)d.items_cap * 2u));
         HIP_TRY(c, hipMemset(d.route_pairs_big, 0, sizeof(uint32_t) * (size_t)d.items_cap * 2u));
         {
+            // (a school building's records are those of everybody who works or learns there: its members are in the room lists)
+            std::vector<uint32_t> sch_members((size_t)B + 1, 0);
+            for (uint32_t i = 0; i < N; ++i) if (fl[i] & FL_WORK_SCHOOL) sch_members[pop->work_building[i] + 1]++;
+            for (uint32_t b = 0; b < B; ++b) sch_members[b + 1] += sch_members[b];
             std::vector<uint32_t> ovf_off(res_off.size());
-            for (size_t i = 0; i < res_off.size(); ++i) ovf_off[i] = res_off[i] + wrk_off[i];
+            for (size_t i = 0; i < res_off.size(); ++i) ovf_off[i] = res_off[i] + wrk_off[i] + sch_members[i];
             if ((rc = dev_upload(c, &d.ovf_off, ovf_off.data(), ovf_off.size()))) return rc;
             d.ovf_room_base = ovf_off.back();
             // (the persistent map keeps two places per member -- a record and a cancellation -- and the routes' riders behind the rooms)
@@ -709,7 +713,7 @@ int device_error(esim_ctx_impl *c)
 {
     Ctrl h;
     HIP_TRY(c, hipMemcpy(&h, c->d.ctrl, sizeof h, hipMemcpyDeviceToHost));
-    if (h.error) return fail(c, -(int)h.error, "device-side error (S underflow / vaccination window exhausted)");
+    if (h.error) return fail(c, -(int)h.error, "device-side error (S underflow / vaccination window exhausted / a chunk table check: " + std::to_string(h.err_where) + ")");
     return ESIM_OK;
 }
 
@@ -772,7 +776,7 @@ int run_sequential(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, ui
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (c->kernel_timing && h.small_done) { float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->sev[0], c->sev[1])); c->small_ms += ms; c->small_steps += h.small_done; }
             c->host_t += h.small_done; total += h.small_done; remaining -= h.small_done;
-            if (h.error) return fail(c, -(int)h.error, "device-side error (S underflow / vaccination window exhausted)");
+            if (h.error) return fail(c, -(int)h.error, "device-side error (S underflow / vaccination window exhausted / a chunk table check: " + std::to_string(h.err_where) + ")");
             if (h.finished && allow_early_stop) break;
         }
         if (remaining == 0) break;
@@ -907,7 +911,7 @@ int run_chunk(esim_ctx_impl *c, uint32_t n_ahead, uint32_t *executed, Ctrl *stat
     HIP_TRY(c, hipMemcpyAsync(&h, d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (state_before) *state_before = h;
-    if (h.error) return fail(c, -(int)h.error, "device-side error");
+    if (h.error) return fail(c, -(int)h.error, "device-side error (raised at check " + std::to_string(h.err_where) + ", esim_device.h ERR_AT_*)");
     const uint32_t n = h.chunk_ok, t0 = h.t;
     c->last_chunk_pairs = h.chunk_pairs;
     *executed = 0;
@@ -974,7 +978,7 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             Ctrl h;
             if ((rc = burst_readback(c, first, std::min<uint32_t>(remaining, bursts * (uint32_t)c->xf_n), &h))) return rc;
             HIP_TRY(c, hipGetLastError());
-            if (h.error) return fail(c, -(int)h.error, "device-side error");
+            if (h.error) return fail(c, -(int)h.error, "device-side error (raised at check " + std::to_string(h.err_where) + ", esim_device.h ERR_AT_*)");
             const uint32_t done = h.t - first;
             c->last_chunk_pairs = h.chunk_pairs;
             if (tk && done) { float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->cev[0], c->cev[1])); c->chunk_ms += ms; c->chunk_steps += done; c->chunk_count += (done + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n; }
@@ -1011,7 +1015,7 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             Ctrl h;
             if ((rc = burst_readback(c, first, std::min<uint32_t>(remaining, bursts * (uint32_t)c->xf_n), &h))) return rc;
             HIP_TRY(c, hipGetLastError());
-            if (h.error) return fail(c, -(int)h.error, "device-side error");
+            if (h.error) return fail(c, -(int)h.error, "device-side error (raised at check " + std::to_string(h.err_where) + ", esim_device.h ERR_AT_*)");
             const uint32_t done = h.t - first;
             c->last_chunk_pairs = h.chunk_pairs;
             if (tk && done) { float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->cev[0], c->cev[1])); c->chunk_ms += ms; c->chunk_steps += done; c->chunk_count += (done + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n; }
@@ -1100,7 +1104,7 @@ extern "C" int esim_run(esim_ctx *ctx, uint32_t n_steps, int stop_when_done, esi
     Ctrl h;
     if (c->ctrl_fresh) h = *c->pin_ctrl;
     else if ((rc = read_ctrl(c, &h))) return rc;
-    if (h.error) return fail(c, -(int)h.error, "device-side error (S underflow / vaccination window exhausted)");
+    if (h.error) return fail(c, -(int)h.error, "device-side error (S underflow / vaccination window exhausted / a chunk table check: " + std::to_string(h.err_where) + ")");
     const uint32_t done = h.steps_done >= first ? h.steps_done - first + 1 : 0;
     if (std::getenv("ESIM_DEBUG"))
         std::fprintf(stderr, "[esim] esim_run(%u steps from %u): done %u, t=%u steps_done=%u finished=%u chunk_ok=%u parallel=%u, records mirrored %u, control block %s\n",
@@ -1576,7 +1580,7 @@ extern "C" int esim_free_collect(esim_ctx *ctx, uint32_t *n_done)
     Ctrl h;
     HIP_TRY(c, hipMemcpyAsync(&h, c->d.ctrl, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (h.error) return fail(c, -(int)h.error, "device-side error");
+    if (h.error) return fail(c, -(int)h.error, "device-side error (raised at check " + std::to_string(h.err_where) + ", esim_device.h ERR_AT_*)");
     const uint32_t done = h.t - c->free_first;
     c->last_chunk_pairs = h.chunk_pairs;
     // device time of the chunks of the burst (k_future and the collective in front of each are not inside the pairs)

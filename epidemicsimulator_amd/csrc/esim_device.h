@@ -114,6 +114,7 @@ struct Ctrl {
     uint32_t n_neg;             // cancellation records appended for this chunk's plan (Dev::neg_list)
     uint32_t pmap_chunk;        // the chunk in flight runs on the persistent map (k_map_enter decided)
     uint32_t prev_pmap;         // ... and the chunk k_chunk_scatter is finishing did
+    uint32_t err_where;         // diagnostics: which check raised `error` (ERR_AT_*), reported in esim_last_error
     uint32_t peer_error;        // sharded runs: the error fields of ALL shards, summed (ERR_FIELD): every rank takes its return code
                                 // from this word, so that all leave esim_run_sharded together (k_status_unpack)
 };
@@ -281,6 +282,10 @@ struct Dev {
 #define HOT_PREV_NEWEXP 193u       // [SUBQ] copy of HOT_NEWEXP of the chunk whose log entries k_chunk_scatter is writing
 #define HOT_RESET 193u             // counters k_decide zeroes for a new chunk
 #define HOT_COUNT 257u
+// where a device-side error was raised (Ctrl::err_where)
+#define RAISE(ctrl, code, where) do { (ctrl)->error = (uint32_t)(-(code)); (ctrl)->err_where = (where); } while (0)
+enum { ERR_AT_OVF_FULL = 1, ERR_AT_BIG_LIST, ERR_AT_NEG_LIST, ERR_AT_ITEM_IDS, ERR_AT_HASH_FULL, ERR_AT_ITEM_CHECK, ERR_AT_ROUTE_ITEM, ERR_AT_MAP_STATE,
+       ERR_AT_CANCEL_SLOT, ERR_AT_BIGPAIRS };
 #define NEG_CAP (1u << 18)          // cancellation records per chunk (a chunk plans at most 96 x 8192 vaccinations, few of them of Infected citizens)
 #define UNIT_NOOP 0xFFFFFFFFu
 #define CHUNK_BUS_STEPS 8u         // a one-pass chunk has at most this many steps with riders on a bus

@@ -666,18 +666,18 @@ __device__ __forceinline__ void map_append(const Dev &d, Ctrl *ctrl, uint32_t sl
     if (!all_ovf && pos < ITEM_RECS) { where = slot * SLOT_IV_STRIDE + pos; d.slot_iv[where] = rec; }
     else {
         const uint32_t q = all_ovf ? pos : pos - ITEM_RECS;
-        if (q >= cap2) { ctrl->error = (uint32_t)(-ESIM_ERANGE); return; }     // (a member leaves one record and at most one cancellation per item)
+        if (q >= cap2) { RAISE(ctrl, ESIM_ERANGE, ERR_AT_OVF_FULL); return; }     // (a member leaves one record and at most one cancellation per item)
         d.ovf[base2 + q] = rec;
         where = 0x80000000u | (base2 + q);
         if (q == 0u) {
             const uint32_t r = wave & (SUBQ - 1u), at = atomicAdd(&d.pbig_cnt[r], 1u);
             if (at < d.big_qcap) { uint32_t *bl = d.big_list + ((size_t)r * d.big_qcap + at) * 3u; bl[0] = slot; bl[1] = base2; bl[2] = cap2 | (all_ovf ? 0x80000000u : 0u); }
-            else ctrl->error = (uint32_t)(-ESIM_ERANGE);
+            else RAISE(ctrl, ESIM_ERANGE, ERR_AT_BIG_LIST);
         }
     }
     if (rec & PIV_NEG) {
         const uint32_t i = atomicAdd(&ctrl->n_neg, 1u);
-        if (i < NEG_CAP) { d.neg_list[2u * i] = where; d.neg_list[2u * i + 1u] = neg_step; } else ctrl->error = (uint32_t)(-ESIM_ERANGE);
+        if (i < NEG_CAP) { d.neg_list[2u * i] = where; d.neg_list[2u * i + 1u] = neg_step; } else RAISE(ctrl, ESIM_ERANGE, ERR_AT_NEG_LIST);
     }
 }
 
@@ -691,7 +691,7 @@ __device__ __forceinline__ uint32_t map_slot(const Dev &d, Ctrl *ctrl, unsigned 
         if (seen == key) return h;
         h = (h + 1u) & (d.hcap - 1u);
     }
-    ctrl->error = (uint32_t)(-ESIM_ERANGE);
+    RAISE(ctrl, ESIM_ERANGE, ERR_AT_HASH_FULL);
     return ITEM_UNUSED;
 }
 
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(TPB) void k_map_enter(Dev d)
     const uint32_t wave = (blockIdx.x * TPB + threadIdx.x) >> 6, n_waves = (gridDim.x * TPB) >> 6;
     const uint32_t map_t = ctrl->map_t;
     const bool rebuild = map_t != t0;
-    if (rebuild && map_t != 0xFFFFFFFFu) { if (wave == 0 && lane == 0) ctrl->error = (uint32_t)(-ESIM_ESTATE); return; }   // (the host clears before a rebuild)
+    if (rebuild && map_t != 0xFFFFFFFFu) { if (wave == 0 && lane == 0) RAISE(ctrl, ESIM_ESTATE, ERR_AT_MAP_STATE); return; }   // (the host clears before a rebuild)
     {
         const uint32_t q = (t0 + MARK_SLOTS - 1u) & (MARK_SLOTS - 1u);        // marks a sequential step left (see k_chunk_marks)
         const uint32_t tid = blockIdx.x * TPB + threadIdx.x, nth = gridDim.x * TPB;
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(TPB) void k_map_enter(Dev d)
         if (n_claims) {
             if (lane == 0) first_id = atomicAdd(&d.used_cnt[sub], n_claims);
             first_id = FX(first_id, 0);
-            if (first_id + n_claims > per) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); n_claims = 0u; }
+            if (first_id + n_claims > per) { if (lane == 0) RAISE(ctrl, ESIM_ERANGE, ERR_AT_ITEM_IDS); n_claims = 0u; }
         }
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) {
@@ -831,7 +831,7 @@ __device__ __forceinline__ void map_cancel(const Dev &d, Ctrl *ctrl, uint32_t c,
     for (uint32_t k = 0; k < 4u; ++k) {
         if (!use[k]) continue;
         const uint32_t slot = map_slot(d, ctrl, (unsigned long long)id[k] + (k == 2u ? d.n_bld : k == 3u ? d.n_bld + d.n_room : 0u), false);
-        if (slot == ITEM_UNUSED) { ctrl->error = (uint32_t)(-ESIM_ESTATE); continue; }     // (its record is there: CW_IN_MAP)
+        if (slot == ITEM_UNUSED) { RAISE(ctrl, ESIM_ESTATE, ERR_AT_CANCEL_SLOT); continue; }     // (its record is there: CW_IN_MAP)
         uint32_t base2, cap2;
         map_ovf_range(d, k, id[k], base2, cap2);
         const uint32_t pos = atomicAdd(&d.slot_state[slot], 1u) & PSLOT_COUNT;
@@ -1711,7 +1711,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
         const uint32_t pq0 = PROF_NOW();
         const ItemFetch it = decode_item<PM>(d, x, lane, n, ct, AW, BUS);
         if (it.slot == ITEM_UNUSED) continue;
-        if (!item_ok(d, it)) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); continue; }
+        if (!item_ok(d, it)) { if (lane == 0) RAISE(ctrl, ESIM_ERANGE, ERR_AT_ITEM_CHECK); continue; }
         // (persistent map: an item whose records all lie outside the chunk -- recovered, or at home under a lockdown -- is left
         // here, before any member is fetched)
         if (PM && !__any((it.c0 | it.c1) != 0u)) continue;
@@ -1719,7 +1719,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
             if (PM) {
                 // the bus steps in which an Infected rider of this route is on the bus: c0 / c1 count them per step
                 const uint32_t r = it.id - route_base, sz = it.a_hi - it.a_lo;
-                if (r >= d.n_routes || it.a_hi < it.a_lo || it.a_hi > d.n_pt) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); continue; }
+                if (r >= d.n_routes || it.a_hi < it.a_lo || it.a_hi > d.n_pt) { if (lane == 0) RAISE(ctrl, ESIM_ERANGE, ERR_AT_ROUTE_ITEM); continue; }
                 const unsigned long long m_lo = __ballot(it.c0 != 0u) & BUS.lo;
                 const uint32_t m_hi = (uint32_t)__ballot(lane < FREE_MAX - 64u && it.c1 != 0u) & BUS.hi;
                 if (sz <= 64u) {
@@ -1730,7 +1730,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
                     uint32_t at = 0u;
                     if (lane == 0) at = atomicAdd(&d.hot[HOT_BIGPAIRS * HOT_STRIDE], np);
                     at = FX(at, 0);
-                    if (at + np > 2u * d.items_cap) { if (lane == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); continue; }
+                    if (at + np > 2u * d.items_cap) { if (lane == 0) RAISE(ctrl, ESIM_ERANGE, ERR_AT_BIGPAIRS); continue; }
                     uint32_t i = 0u;
                     for (unsigned long long m = m_lo; m; m &= m - 1ull, ++i) if (lane == 0) d.route_pairs_big[at + i] = (r << 7) | (uint32_t)__builtin_ctzll(m);
                     for (uint32_t m = m_hi; m; m &= m - 1u, ++i) if (lane == 0) d.route_pairs_big[at + i] = (r << 7) | (64u + (uint32_t)__builtin_ctz(m));
