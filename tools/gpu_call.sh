@@ -26,6 +26,14 @@ for step in $steps; do
     pmap) ESIM_PMAP_REBUILD=1 timeout -k 10 300 python tools/fuzz_parity.py 2000 40 > gpurun_out/fuzz_pm1_$tag.log 2>&1; rc=$?; tail -3 gpurun_out/fuzz_pm1_$tag.log; [ $rc -eq 0 ] || exit $rc
           timeout -k 10 300 python tools/fuzz_parity.py 2000 40 > gpurun_out/fuzz_pm4_$tag.log 2>&1; rc=$?; tail -3 gpurun_out/fuzz_pm4_$tag.log; [ $rc -eq 0 ] || exit $rc
           ESIM_PMAP_REBUILD=1000 timeout -k 10 300 python tools/fuzz_parity.py 3000 40 > gpurun_out/fuzz_pmx_$tag.log 2>&1; rc=$?; tail -3 gpurun_out/fuzz_pmx_$tag.log; [ $rc -eq 0 ] || exit $rc ;;
+    pmab) for i in 1 2; do
+            echo -n "rebuilt per chunk (old): "; ESIM_PMAP=0 timeout -k 10 200 python tools/run_preset.py uk64m | grep us/step | cut -c1-110 || exit 5
+            for r in 1 2 4 8 1000; do echo -n "persistent, rebuild every $r: "; ESIM_PMAP_REBUILD=$r timeout -k 10 200 python tools/run_preset.py uk64m | grep us/step | cut -c1-110 || exit 5; done
+          done
+          for p in york syn3m5 yh_census; do echo -n "$p old: "; ESIM_PMAP=0 timeout -k 10 200 python tools/run_preset.py $p | grep us/step | cut -c1-110; echo -n "$p persistent: "; timeout -k 10 200 python tools/run_preset.py $p | grep us/step | cut -c1-110; done ;;
+    bigfuzz) timeout -k 10 400 python tools/fuzz_parity.py 9000 16 --big > gpurun_out/fuzz_big_$tag.log 2>&1; rc=$?; tail -2 gpurun_out/fuzz_big_$tag.log; [ $rc -eq 0 ] || exit $rc
+          ESIM_PMAP_REBUILD=1000 timeout -k 10 400 python tools/fuzz_parity.py 9100 16 --big > gpurun_out/fuzz_bigx_$tag.log 2>&1; rc=$?; tail -2 gpurun_out/fuzz_bigx_$tag.log; [ $rc -eq 0 ] || exit $rc
+          ESIM_GRID_CHUNK=16 ESIM_PMAP_REBUILD=3 timeout -k 10 300 python tools/fuzz_parity.py 12000 20 --big > gpurun_out/fuzz_g16_$tag.log 2>&1; rc=$?; tail -1 gpurun_out/fuzz_g16_$tag.log; [ $rc -eq 0 ] || exit $rc ;;
     *) echo "unknown step $step"; exit 9 ;;
   esac
 done
