@@ -34,6 +34,9 @@ for step in $steps; do
     bigfuzz) timeout -k 10 400 python tools/fuzz_parity.py 9000 16 --big > gpurun_out/fuzz_big_$tag.log 2>&1; rc=$?; tail -2 gpurun_out/fuzz_big_$tag.log; [ $rc -eq 0 ] || exit $rc
           ESIM_PMAP_REBUILD=1000 timeout -k 10 400 python tools/fuzz_parity.py 9100 16 --big > gpurun_out/fuzz_bigx_$tag.log 2>&1; rc=$?; tail -2 gpurun_out/fuzz_bigx_$tag.log; [ $rc -eq 0 ] || exit $rc
           ESIM_GRID_CHUNK=16 ESIM_PMAP_REBUILD=3 timeout -k 10 300 python tools/fuzz_parity.py 12000 20 --big > gpurun_out/fuzz_g16_$tag.log 2>&1; rc=$?; tail -1 gpurun_out/fuzz_g16_$tag.log; [ $rc -eq 0 ] || exit $rc ;;
+    ktimes) ESIM_PMAP=0 timeout -k 10 200 python tools/kernel_times.py uk64m || exit 5
+            ESIM_PMAP_REBUILD=1 timeout -k 10 200 python tools/kernel_times.py uk64m || exit 5
+            ESIM_PMAP_REBUILD=4 timeout -k 10 200 python tools/kernel_times.py uk64m || exit 5 ;;
     *) echo "unknown step $step"; exit 9 ;;
   esac
 done
