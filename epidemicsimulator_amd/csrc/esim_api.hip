@@ -189,6 +189,7 @@ extern "C" int esim_create(const esim_params *p, esim_ctx **out)
     if (!p || !out) return fail(nullptr, ESIM_EINVAL, "esim_create: null argument");
     if (p->exposed_time + p->infected_time + 2u > TE_BIAS)
         return fail(nullptr, ESIM_ERANGE, "esim_create: exposed_time + infected_time + 2 exceeds the state encoding (512)");
+    static_assert(SCH_RING >= TE_BIAS + 2u * FREE_MAX, "the school rings must hold an Infected window and two chunks");
     if (p->vaccination_rate > VACC_MAX_RATE)
         return fail(nullptr, ESIM_ERANGE, "esim_create: vaccination_rate above 8192 is not supported");
     if (p->bus_capacity == 0 || p->start_hour == 0 || p->end_hour == 0 || p->start_hour > 24 || p->end_hour > 24)
@@ -440,6 +441,15 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
             std::vector<uint32_t> ovf_off(res_off.size());
             for (size_t i = 0; i < res_off.size(); ++i) ovf_off[i] = res_off[i] + wrk_off[i] + sch_members[i];
             if ((rc = dev_upload(c, &d.ovf_off, ovf_off.data(), ovf_off.size()))) return rc;
+            {
+                std::vector<int32_t> sch_of(B ? B : 1, -1);
+                uint32_t n_sch = 0;
+                for (uint32_t b = 0; b < B; ++b) if (pop->building_type[b] == ESIM_SCHOOL) sch_of[b] = (int32_t)n_sch++;
+                d.n_sch = n_sch;
+                if ((rc = dev_upload(c, &d.sch_of_bld, sch_of.data(), sch_of.size()))) return rc;
+                if ((rc = dev_alloc(c, &d.sch_ring, (size_t)(n_sch ? n_sch : 1) * 2u * SCH_RING))) return rc;
+                HIP_TRY(c, hipMemset(d.sch_ring, 0, sizeof(uint32_t) * (size_t)(n_sch ? n_sch : 1) * 2u * SCH_RING));
+            }
             d.ovf_room_base = ovf_off.back();
             // (the persistent map keeps two places per member -- a record and a cancellation -- and the routes' riders behind the rooms)
             d.ovf_route_base = d.ovf_room_base + room_off.back();
@@ -453,6 +463,8 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if ((rc = dev_alloc(c, &d.used_pref, CHUNK_WAVES_MAX + 1u))) return rc;
         if ((rc = dev_alloc(c, &d.pbig_cnt, SUBQ))) return rc;
         if ((rc = dev_alloc(c, &d.neg_list, (size_t)NEG_CAP * 2u))) return rc;
+        if ((rc = dev_alloc(c, &d.cancel_list, (size_t)NEG_CAP * 2u))) return rc;
+        HIP_TRY(c, hipMemset(d.cancel_list, 0, sizeof(uint32_t) * (size_t)NEG_CAP * 2u));
         HIP_TRY(c, hipMemset(d.pbig_cnt, 0, sizeof(uint32_t) * SUBQ));
         HIP_TRY(c, hipMemset(d.neg_list, 0, sizeof(uint32_t) * (size_t)NEG_CAP * 2u));
         HIP_TRY(c, hipMemset(d.big_list, 0, sizeof(uint32_t) * (size_t)d.big_qcap * SUBQ * 3u));
@@ -831,6 +843,7 @@ void enqueue_chunk_front(esim_ctx_impl *c)
             kd_mark(c, ESIM_CK_MAP_CLEAR);
             hipLaunchKernelGGL(k_map_clear, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
             hipLaunchKernelGGL(k_map_reset, dim3(1), dim3(64), 0, c->stream, d);
+            (void)hipMemsetAsync(d.sch_ring, 0, sizeof(uint32_t) * (size_t)(d.n_sch ? d.n_sch : 1) * 2u * SCH_RING, c->stream);
             c->pmap_since_rebuild = 0;
         }
         c->map_valid = true; c->pmap_used = true; c->pmap_since_rebuild++;
@@ -881,6 +894,7 @@ void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
         kd_mark(c, ESIM_CK_MAP_CLEAR);
         hipLaunchKernelGGL(k_map_clear, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
         hipLaunchKernelGGL(k_map_reset, dim3(1), dim3(64), 0, c->stream, d);
+        (void)hipMemsetAsync(d.sch_ring, 0, sizeof(uint32_t) * (size_t)(d.n_sch ? d.n_sch : 1) * 2u * SCH_RING, c->stream);
         c->pmap_since_rebuild = 0; c->map_valid = true;
     }
     kd_mark(c, ESIM_CK_VAX_ADJ);
@@ -987,6 +1001,7 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             if (h.finished && allow_early_stop) break;
             if (remaining == 0) break;
             if (done) { vax_fail = 0; continue; }                       // (cut chunks advance less; the next one starts at the cut)
+            c->map_valid = false;                                        // (no progress: whatever the reason, the map is rebuilt next)
             if (std::getenv("ESIM_DEBUG"))
                 std::fprintf(stderr, "[esim] vax burst without progress at t=%u: chunk_ok=%u parallel=%u vax_chunk=%u cut=%u pairs=%u fits_flag=%u elig=%u bursts=%u\n",
                              h.t, h.chunk_ok, h.chunk_parallel, h.vax_chunk, h.chunk_cut, h.chunk_pairs, 0u, h.elig_count, bursts);
@@ -1021,7 +1036,7 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             if (tk && done) { float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->cev[0], c->cev[1])); c->chunk_ms += ms; c->chunk_steps += done; c->chunk_count += (done + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n; }
             c->host_t = h.t; total += done; remaining -= done;
             if (h.finished) break;
-            if (done == 0) { backoff = std::min<uint32_t>(64u, backoff ? backoff * 2u : 1u); sync_chunks_left = backoff; probing = true; }
+            if (done == 0) { backoff = std::min<uint32_t>(64u, backoff ? backoff * 2u : 1u); sync_chunks_left = backoff; probing = true; c->map_valid = false; }   // (e.g. a map built under a lockdown: rebuilt next)
             else { backoff = 0; probing = done < std::min<uint32_t>(remaining + done, bursts * (uint32_t)c->xf_n); }
             if (done < std::min<uint32_t>(remaining + done, bursts * (uint32_t)c->xf_n)) stalled = true;   // something other than a full time-parallel chunk is next
             continue;
@@ -1465,6 +1480,7 @@ extern "C" int esim_run_sharded(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_don
     if (c->pmap_used) {                              // (a persistent map left by esim_run: the chunk pass of sharded runs builds its own per chunk)
         hipLaunchKernelGGL(k_map_clear, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
         hipLaunchKernelGGL(k_map_reset, dim3(1), dim3(64), 0, c->stream, d);
+        (void)hipMemsetAsync(d.sch_ring, 0, sizeof(uint32_t) * (size_t)(d.n_sch ? d.n_sch : 1) * 2u * SCH_RING, c->stream);
         c->pmap_used = false;
     }
     c->map_valid = false;
@@ -1967,7 +1983,7 @@ extern "C" int esim_checkpoint_restore(esim_ctx *ctx, const void *buf, size_t by
     h.chunk_ok = 0; h.chunk_parallel = 0; h.chunk_done = 0; h.n_items = 0; h.n_newexp = 0; h.n_units = 0; h.unit_next = 0;
     h.n_route_pairs = 0; h.n_route_pairs_big = 0; h.prev_n_items = 0; h.prev_per_wave = 0; h.items_per_wave = 0; h.small_done = 0;
     h.free_base = 0; h.n_riders = 0; h.peer_error = 0;
-    h.map_t = 0; h.pmap_chunk = 0; h.prev_pmap = 0; h.n_neg = 0;        // (the item map is derived state: the next chunk rebuilds it)
+    h.map_t = 0; h.pmap_chunk = 0; h.prev_pmap = 0; h.n_neg = 0; h.n_cancel = 0; h.map_work = 0;        // (the item map is derived state: the next chunk rebuilds it)
     for (int z = 0; z < 5; ++z) h.counts[z] = 0;
     // marks of the last step are only ever cleared, never read, by the step after it: start without them
     for (uint32_t z = 0; z < MARK_SLOTS; ++z) { h.n_touched_bld[z] = 0; h.n_touched_room[z] = 0; h.n_touched_route[z] = 0; h.n_touched_route_big[z] = 0; }

@@ -112,8 +112,10 @@ struct Ctrl {
     uint32_t map_t;
     uint32_t chunk_e0;          // log entries [chunk_e0, chunk_i1): exposure steps that BECOME Infected in some step of the chunk (k_decide)
     uint32_t n_neg;             // cancellation records appended for this chunk's plan (Dev::neg_list)
+    uint32_t n_cancel;          // planned vaccinations of citizens the map holds (Dev::cancel_list), noted by k_chunk_vax_adj
     uint32_t pmap_chunk;        // the chunk in flight runs on the persistent map (k_map_enter decided)
     uint32_t prev_pmap;         // ... and the chunk k_chunk_scatter is finishing did
+    uint32_t map_work;          // the map holds work buildings, rooms and routes too (it was built for a schedule with working hours)
     uint32_t err_where;         // diagnostics: which check raised `error` (ERR_AT_*), reported in esim_last_error
     uint32_t peer_error;        // sharded runs: the error fields of ALL shards, summed (ERR_FIELD): every rank takes its return code
                                 // from this word, so that all leave esim_run_sharded together (k_status_unpack)
@@ -201,6 +203,13 @@ struct Dev {
     // this chunk's cancellation records (so that those of uncommitted steps can be taken back)
     uint32_t *pbig_cnt;         // [SUBQ]
     uint32_t *neg_list;         // [NEG_CAP][2] word index (bit 31: in `ovf`, else in `slot_iv`), step of the chunk
+    uint32_t *cancel_list;      // [NEG_CAP][2] citizen, step of the chunk
+    // school buildings of the persistent map: instead of one record per Infected member (hundreds in one list when the epidemic
+    // sits in a few catchments), two histograms of exposure steps per school -- everybody, and those who ride public transport --
+    // in rings of SCH_RING steps: how many members are Infected in a step is a window sum over them, like the census
+    const int32_t *sch_of_bld;  // [n_bld] dense school index, -1: not a school
+    uint32_t *sch_ring;         // [n_sch][2][SCH_RING]
+    uint32_t n_sch;
     uint32_t ovf_route_base;    // records of a route's Infected riders: ovf[2 * (ovf_route_base + route_off[r]) ...)
     uint32_t *big_list;         // [SUBQ][big_qcap][3] slots with records in `ovf`, where those start and how many fit, listed by the first
                                 // to put one there; 64 lists by listing wavefront & 63, lengths in hot[HOT_BIG ...]
@@ -286,6 +295,8 @@ struct Dev {
 #define RAISE(ctrl, code, where) do { (ctrl)->error = (uint32_t)(-(code)); (ctrl)->err_where = (where); } while (0)
 enum { ERR_AT_OVF_FULL = 1, ERR_AT_BIG_LIST, ERR_AT_NEG_LIST, ERR_AT_ITEM_IDS, ERR_AT_HASH_FULL, ERR_AT_ITEM_CHECK, ERR_AT_ROUTE_ITEM, ERR_AT_MAP_STATE,
        ERR_AT_CANCEL_SLOT, ERR_AT_BIGPAIRS };
+#define SCH_RING 1024u             // >= exposed_time + infected_time + 2 + 2 * FREE_MAX
+#define PBIG_STRIDE 4u             // words per entry of the persistent map's fold list: slot, overflow base, capacity | school flag, school
 #define NEG_CAP (1u << 18)          // cancellation records per chunk (a chunk plans at most 96 x 8192 vaccinations, few of them of Infected citizens)
 #define UNIT_NOOP 0xFFFFFFFFu
 #define CHUNK_BUS_STEPS 8u         // a one-pass chunk has at most this many steps with riders on a bus

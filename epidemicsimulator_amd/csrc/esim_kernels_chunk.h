@@ -308,7 +308,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead
         if (j == 0) {
             ctrl->vax_chunk = plan ? 1u : 0u;
             ctrl->vax_planned = plan ? n_ahead : 0u;
-            ctrl->n_neg = 0u;
+            ctrl->n_neg = 0u; ctrl->n_cancel = 0u;
             if (!sharded) ctrl->vax_fail = 0u;
             ctrl->chunk_cut = FREE_MAX + 1u;
             for (uint32_t z = FREE_MAX; z < FREE_MAX + 2u; ++z) { d.xf_adj[z] = 0u; for (uint32_t q = 0; q < 4u; ++q) d.vax_delta[q * (FREE_MAX + 2u) + z] = 0u; }
@@ -398,7 +398,11 @@ __global__ __launch_bounds__(TPB) void k_chunk_vax_adj(Dev d, uint32_t max_ahead
         if (lo <= hi) { atomicSub(&d.xf_adj[lo], 1u); atomicAdd(&d.xf_adj[hi + 1], 1u); }
         // persistent map: a citizen it holds already (k_map_enter handles those that turn Infected in this chunk) and whose stretch
         // reaches beyond step j is cancelled from step j + 1 on -- to the end of its stretch, whatever the chunk's length
-        if (pmap && (w & CW_IN_MAP) && ctrl->map_t == t0 && a + (int)d.infected_time > (int)j) map_cancel(d, const_cast<Ctrl *>(ctrl), cz, w, t0, j);
+        // (noted here, entered by k_map_enter once the chunk's length is known: a step beyond its end is not committed by it)
+        if (pmap && (w & CW_IN_MAP) && ctrl->map_t == t0 && a + (int)d.infected_time > (int)j) {
+            const uint32_t q = atomicAdd(&const_cast<Ctrl *>(ctrl)->n_cancel, 1u);
+            if (q < NEG_CAP) { d.cancel_list[2u * q] = cz; d.cancel_list[2u * q + 1u] = j; } else RAISE(const_cast<Ctrl *>(ctrl), ESIM_ERANGE, ERR_AT_NEG_LIST);
+        }
     }
 }
 
@@ -640,14 +644,13 @@ __global__ __launch_bounds__(TPB) void k_map_clear(Dev d)
         for (uint32_t k = tid; k < cnt; k += nth) {
             const uint32_t v = s * per + k, h = d.hitems[v];
             if (h >= d.hcap) continue;
-            if ((d.slot_state[h] & PSLOT_COUNT) > ITEM_RECS || (d.item_rec[v].id < d.n_bld && d.item_rec[v].aux == ESIM_SCHOOL))
-                for (uint32_t j = 0; j < FREE_MAX; ++j) d.vec[(size_t)h * FREE_MAX + j] = 0u;
+            // (the per-step counters need no zeroing: on the persistent map k_map_fold STORES them before anybody reads them)
             d.hkey[h] = HKEY_EMPTY; d.slot_state[h] = 0u; d.hitems[v] = ITEM_UNUSED;
         }
     }
     const int lo_te = (int)(ctrl->t + TE_BIAS) - (int)d.exposed_time - 1 - (int)d.infected_time;
     const uint32_t i0 = d.log_off[lo_te < 0 ? 0 : lo_te], i1 = ctrl->log_len;
-    for (uint32_t i = i0 + tid; i < i1; i += nth) { const uint32_t c = d.log[i]; if (d.cit[c] & CW_IN_MAP) atomicAnd(&d.cit[c], ~CW_IN_MAP); }
+    for (uint32_t i = i0 + tid; i < i1; i += nth) { const uint32_t c = d.log[i], w = d.cit[c]; if (w & CW_IN_MAP) d.cit[c] = w & ~CW_IN_MAP; }   // (nothing else runs)
 }
 __global__ __launch_bounds__(64) void k_map_reset(Dev d)
 {
@@ -659,6 +662,12 @@ __global__ __launch_bounds__(64) void k_map_reset(Dev d)
 // One record of a citizen into one slot of the persistent map; returns nothing the caller has to wait for.  kind 0 home building,
 // 1 work building, 2 room, 3 route; all_ovf: a school building (every record in `ovf`).  A first record in `ovf` lists the slot
 // for k_map_fold; a cancellation record notes its address in Dev::neg_list.
+__device__ __forceinline__ void map_list(const Dev &d, Ctrl *ctrl, uint32_t slot, uint32_t base2, uint32_t cap2, uint32_t sch, uint32_t wave)
+{
+    const uint32_t r = wave & (SUBQ - 1u), at = atomicAdd(&d.pbig_cnt[r], 1u), cap = d.big_qcap * 3u / PBIG_STRIDE;
+    if (at < cap) { uint32_t *bl = d.big_list + ((size_t)r * cap + at) * PBIG_STRIDE; bl[0] = slot; bl[1] = base2; bl[2] = cap2 | (sch != 0xFFFFFFFFu ? 0x80000000u : 0u); bl[3] = sch; }
+    else RAISE(ctrl, ESIM_ERANGE, ERR_AT_BIG_LIST);
+}
 __device__ __forceinline__ void map_append(const Dev &d, Ctrl *ctrl, uint32_t slot, uint32_t pos, uint32_t rec, uint32_t base2, uint32_t cap2, bool all_ovf,
                                             uint32_t wave, uint32_t neg_step)
 {
@@ -669,11 +678,7 @@ __device__ __forceinline__ void map_append(const Dev &d, Ctrl *ctrl, uint32_t sl
         if (q >= cap2) { RAISE(ctrl, ESIM_ERANGE, ERR_AT_OVF_FULL); return; }     // (a member leaves one record and at most one cancellation per item)
         d.ovf[base2 + q] = rec;
         where = 0x80000000u | (base2 + q);
-        if (q == 0u) {
-            const uint32_t r = wave & (SUBQ - 1u), at = atomicAdd(&d.pbig_cnt[r], 1u);
-            if (at < d.big_qcap) { uint32_t *bl = d.big_list + ((size_t)r * d.big_qcap + at) * 3u; bl[0] = slot; bl[1] = base2; bl[2] = cap2 | (all_ovf ? 0x80000000u : 0u); }
-            else RAISE(ctrl, ESIM_ERANGE, ERR_AT_BIG_LIST);
-        }
+        if (q == 0u && !all_ovf) map_list(d, ctrl, slot, base2, cap2, 0xFFFFFFFFu, wave);     // (a school is listed by its first member, see k_map_enter)
     }
     if (rec & PIV_NEG) {
         const uint32_t i = atomicAdd(&ctrl->n_neg, 1u);
@@ -729,11 +734,27 @@ __global__ __launch_bounds__(TPB) void k_map_enter(Dev d)
         for (uint32_t i = tid; i < orb; i += nth) d.route_flag[q][d.touched_route_big[q][i]] = 0u;
     }
     const uint32_t per = d.items_cap / SUBQ;
-    if (wave == 0 && lane == 0) { ctrl->items_per_wave = per; ctrl->n_items = per * SUBQ; ctrl->pmap_chunk = 1u; }
+    // Work building, room and route are entered only into a map that is built for a schedule with working hours: under a lockdown
+    // (everybody at home for the whole chunk, Q8) a rebuild enters the homes alone -- half the items --, and a chunk whose schedule
+    // needs the others cannot run on such a map: it is a no-op, the host sees no progress and rebuilds.
+    const Decision q0 = lane < n ? d.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
+    const Decision q1 = 64u + lane < n ? d.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
+    const bool needs_work = __ballot(lane < n && (q0.at_work | q0.bus_dir) != 0u) != 0ull || __ballot(64u + lane < n && (q1.at_work | q1.bus_dir) != 0u) != 0ull;
+    const bool map_work = rebuild ? needs_work : ctrl->map_work != 0u;
+    if (needs_work && !map_work) { if (wave == 0 && lane == 0) ctrl->chunk_parallel = 0u; return; }
+    if (wave == 0 && lane == 0) { ctrl->items_per_wave = per; ctrl->n_items = per * SUBQ; ctrl->pmap_chunk = 1u; ctrl->map_work = map_work ? 1u : 0u; }
     const uint32_t i0 = rebuild ? ctrl->chunk_i0 : ctrl->chunk_e0, i1 = ctrl->chunk_i1;
     const ChunkT ct = chunk_t(d, t0, n);
     const unsigned long long lt = (1ull << lane) - 1ull;
     const uint32_t sub = wave & (SUBQ - 1u);
+    // the plan's vaccinations of citizens the map holds already (k_chunk_vax_adj noted them), those inside the chunk
+    if (!rebuild) {
+        const uint32_t nc = min(ctrl->n_cancel, NEG_CAP);
+        for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < nc; i += gridDim.x * TPB) {
+            const uint32_t cz = d.cancel_list[2u * i], j = d.cancel_list[2u * i + 1u];
+            if (j < n && cz < d.n) map_cancel(d, ctrl, cz, d.cit[cz], t0, j);
+        }
+    }
     WORK_TALLY;
     const uint32_t E = i1 - i0;
     for (uint32_t round = 0; wave + n_waves * (round * 64u) < E; ++round) {
@@ -743,33 +764,65 @@ __global__ __launch_bounds__(TPB) void k_map_enter(Dev d)
         if (act) { c = d.log[i0 + idx]; w = d.cit[c]; }
         const uint32_t te = CW_TE(w);
         const int a = (int)te - ct.te0;                                        // first Infected step, relative to the chunk
-        const uint32_t vrel = CW_VAX_REL(w);
+        // a vaccination the plan places inside this chunk (one beyond its end is not committed by it: the next plan decides again)
+        const uint32_t vrel = CW_VAX_REL(w) < n ? CW_VAX_REL(w) : CW_VAX_NONE;
         // not (any more) Infected in this chunk; entered already; or Vaccinated (by the chunk's plan) before it would turn Infected
         if (te >= TE_RECOVERED || (w & CW_IN_MAP) || a > (int)n - 1 || a + ct.it < 0 || (vrel != CW_VAX_NONE && (int)vrel < a)) act = false;
         if (act) WORK_ADD(WK_ENTRIES, 1);
-        const bool school = w & FL_WORK_SCHOOL, has_work = w & FL_HAS_WORK;
+        const bool school = w & FL_WORK_SCHOOL, has_work = (w & FL_HAS_WORK) && map_work;
         uint32_t id[4] = { 0u, 0u, 0u, 0u };
         bool use[4] = { act, act && has_work, act && has_work && school, false };
         if (act) id[0] = d.home[c];
         if (use[1]) id[1] = d.work[c];
         if (use[2]) { id[2] = d.room[c]; if (id[2] == 0xFFFFFFFFu) use[2] = false; }
-        if (act && (w & FL_USES_PT)) { id[3] = d.route_of[c]; use[3] = id[3] != NO_ROUTE; }
-        uint32_t slot[4] = { ITEM_UNUSED, ITEM_UNUSED, ITEM_UNUSED, ITEM_UNUSED };
+        if (act && map_work && (w & FL_USES_PT)) { id[3] = d.route_of[c]; use[3] = id[3] != NO_ROUTE; }
+        // find or make the slots: the first probes of all four keys go out together (a look before the compare-and-swap)
+        unsigned long long key[4], seen[4];
+        uint32_t slot[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            key[k] = (unsigned long long)id[k] + (k == 2u ? d.n_bld : k == 3u ? d.n_bld + d.n_room : 0u);
+            slot[k] = hash64(key[k]) & (d.hcap - 1u);
+            seen[k] = key[k];
+            if (use[k]) { WORK_ADD(WK_KEYS, 1); seen[k] = d.hkey[slot[k]]; }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) if (use[k] && seen[k] == HKEY_EMPTY) { seen[k] = atomicCAS(&d.hkey[slot[k]], HKEY_EMPTY, key[k]); if (seen[k] == HKEY_EMPTY) seen[k] = key[k]; }
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k)
-            if (use[k]) {
-                WORK_ADD(WK_KEYS, 1);
-                slot[k] = map_slot(d, ctrl, (unsigned long long)id[k] + (k == 2u ? d.n_bld : k == 3u ? d.n_bld + d.n_room : 0u), true);
-                if (slot[k] == ITEM_UNUSED) use[k] = false;
+            if (use[k] && seen[k] != key[k]) {                                  // somebody else's key in the slot: linear probing from the next one
+                uint32_t h = slot[k];
+                bool found = false;
+                for (uint32_t probe = 1; probe < d.hcap && !found; ++probe) {
+                    h = (h + 1u) & (d.hcap - 1u);
+                    unsigned long long o = d.hkey[h];
+                    if (o == HKEY_EMPTY) { o = atomicCAS(&d.hkey[h], HKEY_EMPTY, key[k]); if (o == HKEY_EMPTY) o = key[k]; }
+                    found = o == key[k];
+                }
+                if (!found) { RAISE(ctrl, ESIM_ERANGE, ERR_AT_HASH_FULL); use[k] = false; }
+                slot[k] = h;
             }
         // the record(s): the citizen's exposure step and what decides where it stands; a plan that vaccinates it at the end of step
         // vrel cancels it from the step after
-        const uint32_t fl = PIV_VALID | te | ((w & FL_USES_PT) ? PIV_PT : 0u) | (has_work ? PIV_HW : 0u);
+        const uint32_t fl = PIV_VALID | te | ((w & FL_USES_PT) ? PIV_PT : 0u) | ((w & FL_HAS_WORK) ? PIV_HW : 0u);
         const bool neg = act && vrel != CW_VAX_NONE && (int)vrel < a + ct.it;   // (to the end of its stretch, whatever the chunk's length)
         const uint32_t cut = neg ? ((t0 + vrel) << PIV_CUT_SHIFT) | PIV_NEG : 0u;
+        // a school building keeps no record per member: the member joins the school's histograms of exposure steps (k_map_fold
+        // sums windows of them); only a cancellation is a record there
+        const bool ring = use[1] && school;
+        int32_t sch = -1;
+        if (ring) {
+            sch = d.sch_of_bld[id[1]];
+            if (sch < 0) { RAISE(ctrl, ESIM_ESTATE, ERR_AT_ITEM_CHECK); use[1] = false; }
+            else {
+                atomicAdd(&d.sch_ring[((size_t)sch * 2u) * SCH_RING + (te & (SCH_RING - 1u))], 1u);
+                if (w & FL_USES_PT) atomicAdd(&d.sch_ring[((size_t)sch * 2u + 1u) * SCH_RING + (te & (SCH_RING - 1u))], 1u);
+            }
+        }
         uint32_t old[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) if (use[k]) old[k] = atomicAdd(&d.slot_state[slot[k]], neg ? 2u : 1u);
+        for (uint32_t k = 0; k < 4u; ++k)
+            if (use[k]) old[k] = (k == 1u && ring) ? atomicAdd(&d.slot_state[slot[k]], neg ? 1u : 0u) : atomicAdd(&d.slot_state[slot[k]], neg ? 2u : 1u);
         // whoever finds a slot that is not listed as an item lists it: the next ids of this wavefront's sub-list
         bool lists[4];
 #pragma unroll
@@ -792,7 +845,7 @@ __global__ __launch_bounds__(TPB) void k_map_enter(Dev d)
                 WORK_ADD(WK_CLAIMS, 1);
                 const uint32_t v = sub * per + first_id + before++;
                 d.hitems[v] = slot[k];
-                ItemRec rec = { id[k] + (k == 2u ? d.n_bld : k == 3u ? d.n_bld + d.n_room : 0u), 0u, 0u, 0u, 0u, 0u, k == 2u ? slot[1] : 0xFFFFFFFFu, 0u };
+                ItemRec rec = { (uint32_t)key[k], 0u, 0u, 0u, 0u, 0u, k == 2u ? slot[1] : 0xFFFFFFFFu, 0u };
                 if (k < 2u) {
                     rec.a_lo = d.res_off[id[k]]; rec.a_hi = d.res_off[id[k] + 1u];
                     rec.b_lo = d.wrk_off[id[k]]; rec.b_hi = d.wrk_off[id[k] + 1u];
@@ -805,14 +858,18 @@ __global__ __launch_bounds__(TPB) void k_map_enter(Dev d)
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) {
             if (!use[k]) continue;
-            WORK_ADD(WK_RECORDS, 1);
             uint32_t base2, cap2;
             map_ovf_range(d, k, id[k], base2, cap2);
             const uint32_t rec = fl | (k == 3u ? PIV_ROUTE : (k == 0u ? 0u : PIV_AS_WORK));
-            const bool all_ovf = k == 1u && school;
             const uint32_t pos = old[k] & PSLOT_COUNT;
-            map_append(d, ctrl, slot[k], pos, rec, base2, cap2, all_ovf, wave, 0u);
-            if (neg) map_append(d, ctrl, slot[k], pos + 1u, rec | cut, base2, cap2, all_ovf, wave, vrel);
+            if (k == 1u && ring) {
+                if (lists[k]) map_list(d, ctrl, slot[k], base2, cap2, (uint32_t)sch, wave);      // (who lists the item lists the school for the fold)
+                if (neg) map_append(d, ctrl, slot[k], pos, rec | cut, base2, cap2, true, wave, vrel);
+                continue;
+            }
+            WORK_ADD(WK_RECORDS, 1);
+            map_append(d, ctrl, slot[k], pos, rec, base2, cap2, false, wave, 0u);
+            if (neg) map_append(d, ctrl, slot[k], pos + 1u, rec | cut, base2, cap2, false, wave, vrel);
         }
         if (act) atomicOr(&d.cit[c], CW_IN_MAP);
     }
@@ -824,9 +881,10 @@ __global__ __launch_bounds__(TPB) void k_map_enter(Dev d)
 __device__ __forceinline__ void map_cancel(const Dev &d, Ctrl *ctrl, uint32_t c, uint32_t w, uint32_t t0, uint32_t j)
 {
     const uint32_t te = CW_TE(w);
-    const bool school = w & FL_WORK_SCHOOL, has_work = w & FL_HAS_WORK;
-    const uint32_t fl = PIV_VALID | PIV_NEG | ((t0 + j) << PIV_CUT_SHIFT) | te | ((w & FL_USES_PT) ? PIV_PT : 0u) | (has_work ? PIV_HW : 0u);
-    uint32_t id[4] = { d.home[c], has_work ? d.work[c] : 0u, (has_work && school) ? d.room[c] : 0xFFFFFFFFu, (w & FL_USES_PT) ? d.route_of[c] : NO_ROUTE };
+    const bool mw = ctrl->map_work != 0u;                                     // (a map built under a lockdown holds the homes alone)
+    const bool school = w & FL_WORK_SCHOOL, has_work = (w & FL_HAS_WORK) && mw;
+    const uint32_t fl = PIV_VALID | PIV_NEG | ((t0 + j) << PIV_CUT_SHIFT) | te | ((w & FL_USES_PT) ? PIV_PT : 0u) | ((w & FL_HAS_WORK) ? PIV_HW : 0u);
+    uint32_t id[4] = { d.home[c], has_work ? d.work[c] : 0u, (has_work && school) ? d.room[c] : 0xFFFFFFFFu, (mw && (w & FL_USES_PT)) ? d.route_of[c] : NO_ROUTE };
     const bool use[4] = { true, has_work, has_work && school && id[2] != 0xFFFFFFFFu, id[3] != NO_ROUTE };
     for (uint32_t k = 0; k < 4u; ++k) {
         if (!use[k]) continue;
@@ -1176,7 +1234,8 @@ __global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
     }
     // list `wave & 63`, every (n_waves / 64)-th entry of it
     const uint32_t qr = wave & (SUBQ - 1u), first = wave >> 6, step = n_waves >> 6;
-    const uint32_t n_list = step ? min(PM ? d.pbig_cnt[qr] : ld(&d.hot[(HOT_BIG + qr) * HOT_STRIDE]), d.big_qcap) : 0u;
+    const uint32_t l_stride = PM ? PBIG_STRIDE : 3u, l_cap = PM ? d.big_qcap * 3u / PBIG_STRIDE : d.big_qcap;
+    const uint32_t n_list = step ? min(PM ? d.pbig_cnt[qr] : ld(&d.hot[(HOT_BIG + qr) * HOT_STRIDE]), l_cap) : 0u;
     const ChunkT ct = chunk_t(d, ctrl->chunk_t0, n);
 #ifdef ESIM_PROFILE_FOLD
     const uint32_t pq0 = PROF_NOW();
@@ -1185,7 +1244,8 @@ __global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
 #endif
     if (first >= n_list) return;
     WORK_TALLY;
-    const uint32_t *bl = d.big_list + (size_t)qr * d.big_qcap * 3u;
+    const uint32_t *bl = d.big_list + (size_t)qr * l_cap * l_stride;
+    __shared__ uint32_t s_win[TPB / 64][2][TE_BIAS + FREE_MAX + 64u];        // (persistent map: a school's window sums, per wavefront)
     const Decision q0 = lane < n ? d.dec[lane] : Decision{ 0u, 0u, 0u, 0u };
     const Decision q1 = 64u + lane < n ? d.dec[64u + lane] : Decision{ 0u, 0u, 0u, 0u };
     const M96 AW = { __ballot(lane < n && q0.at_work != 0u), (uint32_t)__ballot(64u + lane < n && q1.at_work != 0u) };
@@ -1193,11 +1253,12 @@ __global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
     for (uint32_t g = first; g < n_list; g += 64u * step) {
         // 64 of this wavefront's entries at a time, a lane each: the slot, where its records are and how many (those that
         // did not fit counted themselves)
-        uint32_t slot_l = 0u, base_l = 0u, n_ov_l = 0u;
+        uint32_t slot_l = 0u, base_l = 0u, n_ov_l = 0u, sch_l = 0xFFFFFFFFu;
         const uint32_t mine = g + lane * step;
         if (mine < n_list) {
-            slot_l = bl[3u * mine]; base_l = bl[3u * mine + 1u];
-            const uint32_t cap_l = bl[3u * mine + 2u] & 0x7FFFFFFFu, all_ovf = bl[3u * mine + 2u] >> 31;   // (bit 31: a school building of the persistent map)
+            slot_l = bl[l_stride * mine]; base_l = bl[l_stride * mine + 1u];
+            const uint32_t cap_l = bl[l_stride * mine + 2u] & 0x7FFFFFFFu, all_ovf = bl[l_stride * mine + 2u] >> 31;   // (bit 31: a school building of the persistent map)
+            if (PM && all_ovf) { sch_l = bl[l_stride * mine + 3u]; if (sch_l >= d.n_sch) { sch_l = 0xFFFFFFFFu; RAISE(ctrl, ESIM_ERANGE, ERR_AT_BIG_LIST); } }
             if (slot_l < d.hcap && base_l <= d.ovf_n && cap_l <= d.ovf_n - base_l) {
                 const uint32_t state = d.slot_state[slot_l];
                 if (PM) { const uint32_t cnt = state & PSLOT_COUNT, inl = all_ovf ? 0u : ITEM_RECS; n_ov_l = min(cnt > inl ? cnt - inl : 0u, cap_l); }
@@ -1218,6 +1279,42 @@ __global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
             uint32_t iv = ivs[u];
             uint32_t c0 = 0u, c1 = 0u;
             WORK_ADD(WK_FOLDED, lane == 0 ? n_ov : 0);
+            if (PM && FX(sch_l, i) != 0xFFFFFFFFu) {
+                // A school building: its members that are Infected in step j of the chunk are those with exposure steps te0 + j -
+                // infected_time .. te0 + j -- a window sum over its histogram of exposure steps (prefix sums through LDS) --; they
+                // stand there while those with a work place are at work, the riders among them not while riders are on a bus.
+                const uint32_t sch = FX(sch_l, i), wv = threadIdx.x >> 6;
+                const uint32_t *ring = d.sch_ring + (size_t)sch * 2u * SCH_RING;
+                const int base_te = ct.te0 - ct.it;                               // exposure step of the window's low end in step 0
+                const uint32_t len = (uint32_t)ct.it + n;                         // entries base_te .. base_te + len - 1 are needed
+                uint32_t carry0 = 0u, carry1 = 0u;
+                for (uint32_t r0 = 0; r0 < len; r0 += 64u) {
+                    const int te = base_te + (int)(r0 + lane);
+                    uint32_t x0 = (r0 + lane < len && te >= 0) ? ring[(uint32_t)te & (SCH_RING - 1u)] : 0u;
+                    uint32_t x1 = (r0 + lane < len && te >= 0) ? ring[SCH_RING + ((uint32_t)te & (SCH_RING - 1u))] : 0u;
+                    for (uint32_t o = 1; o < 64u; o <<= 1) { const uint32_t y0 = __shfl_up(x0, o, 64), y1 = __shfl_up(x1, o, 64); if (lane >= o) { x0 += y0; x1 += y1; } }
+                    s_win[wv][0][r0 + lane + 1u] = x0 + carry0; s_win[wv][1][r0 + lane + 1u] = x1 + carry1;     // [k + 1] = sum of entries 0 .. k
+                    carry0 += __shfl(x0, 63, 64); carry1 += __shfl(x1, 63, 64);
+                }
+                if (lane == 0) { s_win[wv][0][0] = 0u; s_win[wv][1][0] = 0u; }
+                __builtin_amdgcn_wave_barrier();
+                // step j: entries j .. j + infected_time of the window
+                if (lane < n) {
+                    const uint32_t all = s_win[wv][0][lane + (uint32_t)ct.it + 1u] - s_win[wv][0][lane], pt = s_win[wv][1][lane + (uint32_t)ct.it + 1u] - s_win[wv][1][lane];
+                    c0 = ((AW.lo >> lane) & 1ull) ? all - (((BUS.lo >> lane) & 1ull) ? pt : 0u) : 0u;
+                }
+                if (64u + lane < n) {
+                    const uint32_t j = 64u + lane;
+                    const uint32_t all = s_win[wv][0][j + (uint32_t)ct.it + 1u] - s_win[wv][0][j], pt = s_win[wv][1][j + (uint32_t)ct.it + 1u] - s_win[wv][1][j];
+                    c1 = ((AW.hi >> lane) & 1u) ? all - (((BUS.hi >> lane) & 1u) ? pt : 0u) : 0u;
+                }
+                __builtin_amdgcn_wave_barrier();
+                // the ring's cells below the window are free again for exposure steps SCH_RING later
+                for (uint32_t z = lane; z < 2u * FREE_MAX; z += 64u) {
+                    const int te = base_te - 1 - (int)z;
+                    if (te >= 0) { d.sch_ring[(size_t)sch * 2u * SCH_RING + ((uint32_t)te & (SCH_RING - 1u))] = 0u; d.sch_ring[((size_t)sch * 2u + 1u) * SCH_RING + ((uint32_t)te & (SCH_RING - 1u))] = 0u; }
+                }
+            }
 #ifdef ESIM_PROFILE_FOLD
             pq_rec += n_ov; ++pq_n;
 #endif
@@ -1536,7 +1633,7 @@ __device__ __forceinline__ void pitem_counts(const Dev &d, uint32_t x, uint32_t 
 {
     const uint32_t cnt = FX(x, LANE_STATE) & PSLOT_COUNT;
     c0 = 0u; c1 = 0u;
-    if (vec_only ? cnt > 0u : cnt > ITEM_RECS) {
+    if (vec_only || cnt > ITEM_RECS) {                                     // (a school: k_map_fold stores its counters in every chunk it is listed for)
         if (lane < ct.n) c0 = d.vec[(size_t)slot * FREE_MAX + lane];
         if (64u + lane < ct.n) c1 = d.vec[(size_t)slot * FREE_MAX + 64u + lane];
     }
