@@ -937,8 +937,22 @@ int run_chunk(esim_ctx_impl *c, uint32_t n_ahead, uint32_t *executed, Ctrl *stat
         enqueue_parallel_chunk(c, 0, 0u);
         if (tk) { HIP_TRY(c, hipEventRecord(c->cev[1], c->stream)); HIP_TRY(c, hipEventSynchronize(c->cev[1])); float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->cev[0], c->cev[1])); c->chunk_ms += ms; }
         HIP_TRY(c, hipGetLastError());
-        c->chunk_steps += n; c->chunk_count++;
-        *executed = n;
+        // The chunk takes itself back when the persistent map cannot serve it (k_map_enter: a map built under a lockdown, and a
+        // schedule with working hours): what was executed is read, not assumed; the map is rebuilt and the chunk enqueued again.
+        Ctrl after;
+        int rc2 = read_ctrl(c, &after);
+        if (rc2) return rc2;
+        if (after.error) return fail(c, -(int)after.error, "device-side error (raised at check " + std::to_string(after.err_where) + ")");
+        if (after.t == t0 && c->map_valid) {
+            c->map_valid = false;
+            hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, n_ahead, c->P.max_steps, 1, 0);
+            enqueue_parallel_chunk(c, 0, 0u);
+            if ((rc2 = read_ctrl(c, &after))) return rc2;
+            if (after.error) return fail(c, -(int)after.error, "device-side error (raised at check " + std::to_string(after.err_where) + ")");
+        }
+        const uint32_t ran = after.t - t0;
+        c->chunk_steps += ran; c->chunk_count += ran ? 1u : 0u;
+        *executed = ran;
         return ESIM_OK;
     }
     hipLaunchKernelGGL(k_infected_dec, dim3(c->grid_infected), dim3(TPB), 0, c->stream, d, t0, 0u);
