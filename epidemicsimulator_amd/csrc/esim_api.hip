@@ -575,7 +575,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     if (const char *e = std::getenv("ESIM_GRID_CHUNK")) c->grid_chunk = (uint32_t)std::min((int)(CHUNK_WAVES_MAX * 64u / TPB), std::max(16, std::atoi(e) / 16 * 16));   // whole groups of 64 wavefronts
     if (const char *e = std::getenv("ESIM_PMAP")) c->pmap = std::atoi(e) != 0;
     if (const char *e = std::getenv("ESIM_PMAP_REBUILD")) c->pmap_rebuild_every = (uint32_t)std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("ESIM_DRAW_MULT")) c->draw_mult = (uint32_t)std::min(16, std::max(1, std::atoi(e)));
+    if (const char *e = std::getenv("ESIM_DRAW_MULT")) c->draw_mult = (uint32_t)std::min(4, std::max(1, std::atoi(e)));      // (16 384 wavefronts at most: Dev::pair_cnt)
     if (const char *e = std::getenv("ESIM_UNITS_MULT")) c->units_mult = (uint32_t)std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("ESIM_GRID_EXPOSE")) c->grid_expose = (uint32_t)std::max(1, std::atoi(e));
     c->uploaded = true;
@@ -854,7 +854,7 @@ void enqueue_chunk_front(esim_ctx_impl *c)
         kd_mark(c, ESIM_CK_DRAW);
         hipLaunchKernelGGL(k_chunk_draw<true>, dim3(c->grid_chunk * c->draw_mult), dim3(TPB), 0, c->stream, d, SUBQ);
         kd_mark(c, ESIM_CK_UNITS);
-        hipLaunchKernelGGL(k_chunk_units<true>, dim3(c->grid_chunk * c->units_mult), dim3(TPB), 0, c->stream, d);
+        hipLaunchKernelGGL(k_chunk_units<true>, dim3(c->grid_chunk * c->draw_mult), dim3(TPB), 0, c->stream, d);     // (the same grid as k_chunk_draw: it deals that kernel's route pairs out)
         return;
     }
     c->map_valid = false;

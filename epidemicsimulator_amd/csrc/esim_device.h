@@ -288,9 +288,10 @@ struct Dev {
 #define HOT_UNITS 64u              // [SUBQ] deferred units, by producing wavefront & 63
 #define HOT_BIGPAIRS 128u          // (route, bus step) pairs of routes with more than 64 riders
 #define HOT_BIG 129u               // [SUBQ] slots listed for k_chunk_fold, by listing wavefront & 63
-#define HOT_PREV_NEWEXP 193u       // [SUBQ] copy of HOT_NEWEXP of the chunk whose log entries k_chunk_scatter is writing
-#define HOT_RESET 193u             // counters k_decide zeroes for a new chunk
-#define HOT_COUNT 257u
+#define HOT_PAIRMAX 193u           // [SUBQ] persistent map: the most (route, bus step) pairs a wavefront of k_chunk_draw registered, by wavefront & 63
+#define HOT_PREV_NEWEXP 257u       // [SUBQ] copy of HOT_NEWEXP of the chunk whose log entries k_chunk_scatter is writing
+#define HOT_RESET 257u             // counters k_decide zeroes for a new chunk
+#define HOT_COUNT 321u
 // where a device-side error was raised (Ctrl::err_where)
 #define RAISE(ctrl, code, where) do { (ctrl)->error = (uint32_t)(-(code)); (ctrl)->err_where = (where); } while (0)
 enum { ERR_AT_OVF_FULL = 1, ERR_AT_BIG_LIST, ERR_AT_NEG_LIST, ERR_AT_ITEM_IDS, ERR_AT_HASH_FULL, ERR_AT_ITEM_CHECK, ERR_AT_ROUTE_ITEM, ERR_AT_MAP_STATE,

@@ -822,7 +822,12 @@ __global__ __launch_bounds__(TPB) void k_map_enter(Dev d)
         uint32_t old[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k)
-            if (use[k]) old[k] = (k == 1u && ring) ? atomicAdd(&d.slot_state[slot[k]], neg ? 1u : 0u) : atomicAdd(&d.slot_state[slot[k]], neg ? 2u : 1u);
+            if (use[k]) {
+                // (a school's members -- hundreds in a chunk -- all meet in ONE slot: they look at it with a plain load, and only a
+                // cancellation, which needs a place, or whoever sees it unlisted pays for a returning atomic)
+                if (k == 1u && ring) old[k] = neg ? atomicAdd(&d.slot_state[slot[k]], 1u) : d.slot_state[slot[k]];
+                else old[k] = atomicAdd(&d.slot_state[slot[k]], neg ? 2u : 1u);
+            }
         // whoever finds a slot that is not listed as an item lists it: the next ids of this wavefront's sub-list
         bool lists[4];
 #pragma unroll
@@ -871,7 +876,7 @@ __global__ __launch_bounds__(TPB) void k_map_enter(Dev d)
             map_append(d, ctrl, slot[k], pos, rec, base2, cap2, false, wave, 0u);
             if (neg) map_append(d, ctrl, slot[k], pos + 1u, rec | cut, base2, cap2, false, wave, vrel);
         }
-        if (act) atomicOr(&d.cit[c], CW_IN_MAP);
+        if (act) d.cit[c] = w | CW_IN_MAP;                                    // (nobody else writes the word of a citizen that turns Infected here)
     }
     WORK_FLUSH(d);
 }
@@ -1798,6 +1803,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
     if (lane == 0) ws.rounds = 0u;
 #endif
     uint32_t pst[5] = { 0u, 0u, 0u, 0u, 0u };
+    uint32_t my_pairs = 0u;                                                   // (persistent map: (route, bus step) pairs this wavefront registered)
     const uint32_t pt1 = PROF_NOW();
     // (1) buildings and school rooms: one wavefront per item
     for (uint32_t v = d_lo; v < d_hi; ++v) {
@@ -1820,8 +1826,18 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
                 const unsigned long long m_lo = __ballot(it.c0 != 0u) & BUS.lo;
                 const uint32_t m_hi = (uint32_t)__ballot(lane < FREE_MAX - 64u && it.c1 != 0u) & BUS.hi;
                 if (sz <= 64u) {
-                    for (unsigned long long m = m_lo; m; m &= m - 1ull) route_pair_small(d, ctrl, sm, it.a_lo, sz, (uint32_t)__builtin_ctzll(m), t0, lane WORK_PASS);
-                    for (uint32_t m = m_hi; m; m &= m - 1u) route_pair_small(d, ctrl, sm, it.a_lo, sz, 64u + (uint32_t)__builtin_ctz(m), t0, lane WORK_PASS);
+                    // (registered for k_chunk_units, which deals the pairs of all wavefronts out evenly -- ranked right here they
+                    // made the slowest wavefront twice the median --; a stretch that is full: ranked here after all)
+                    const uint32_t Kd = (uint32_t)(2ull * d.items_cap / n_waves);
+                    uint32_t *list = d.route_pairs + (size_t)wave * Kd;
+                    for (unsigned long long m = m_lo; m; m &= m - 1ull) {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                        if (my_pairs < Kd) { if (lane == 0) list[my_pairs] = (r << 7) | j; ++my_pairs; } else route_pair_small(d, ctrl, sm, it.a_lo, sz, j, t0, lane WORK_PASS);
+                    }
+                    for (uint32_t m = m_hi; m; m &= m - 1u) {
+                        const uint32_t j = 64u + (uint32_t)__builtin_ctz(m);
+                        if (my_pairs < Kd) { if (lane == 0) list[my_pairs] = (r << 7) | j; ++my_pairs; } else route_pair_small(d, ctrl, sm, it.a_lo, sz, j, t0, lane WORK_PASS);
+                    }
                 } else {
                     const uint32_t np = (uint32_t)__popcll(m_lo) + (uint32_t)__popc(m_hi);
                     uint32_t at = 0u;
@@ -1895,6 +1911,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
             route_pair_small(d, ctrl, sm, off, sz, code & 127u, t0, lane WORK_PASS);
         }
     }
+    if (PM && lane == 0) { d.pair_cnt[wave] = my_pairs; if (my_pairs) atomicMax(&d.hot[(HOT_PAIRMAX + (wave & (SUBQ - 1u))) * HOT_STRIDE], my_pairs); }
     WORK_FLUSH(d);
     const uint32_t pt3 = PROF_NOW();
 #ifndef ESIM_PROFILE_UNITS
@@ -1926,7 +1943,10 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
     const uint32_t qr = wave & (SUBQ - 1u), first = wave / SUBQ, step = n_waves / SUBQ;
     const uint32_t n_units = step ? min(ld(&d.hot[(HOT_UNITS + qr) * HOT_STRIDE]), d.unit_qcap) : 0u;
     const uint32_t n_pairs = min(ld(&d.hot[HOT_BIGPAIRS * HOT_STRIDE]), 2u * d.items_cap);
-    if (__syncthreads_or(first < n_units) == 0 && n_pairs == 0u) return;
+    // (persistent map: the pairs of routes of <= 64 riders that k_chunk_draw registered are dealt out here, see below)
+    uint32_t pair_max = 0u;
+    if (PM) { pair_max = ld(&d.hot[(HOT_PAIRMAX + lane) * HOT_STRIDE]); for (int o = 32; o > 0; o >>= 1) pair_max = max(pair_max, __shfl_xor(pair_max, o, 64)); }
+    if (__syncthreads_or(first < n_units) == 0 && n_pairs == 0u && pair_max == 0u) return;
     for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
     for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
     __syncthreads();
@@ -1992,6 +2012,29 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
     PROF_PUT(d, 0, pu0); PROF_PUT(d, 1, pu1); PROF_PUT(d, 2, pu2); PROF_PUT(d, 4, pu_n); PROF_PUT(d, 5, pu_max); PROF_PUT(d, 7, pu_it);
 #endif
     (void)pu0; (void)pu1; (void)pu2; (void)pu_n; (void)pu_max; (void)pu_it;
+    if (PM) {
+        // Wavefront w of k_chunk_draw (same grid) left pair_cnt[w] pairs in its stretch of Kd places; its k-th pair goes to wavefront
+        // (w + k * PAIR_SPREAD) mod n_waves: lane l looks at the stretch it may have been dealt pair k0 + l from, and the wavefront
+        // takes the pairs that exist one by one -- up to the most pairs any wavefront registered.
+        const uint32_t Kd = (uint32_t)(2ull * d.items_cap / n_waves);
+        for (uint32_t k0 = 0; k0 < min(pair_max, Kd); k0 += 64u) {
+            const uint32_t k = k0 + lane;
+            bool have = false;
+            uint32_t code_l = 0u, off_l = 0u, sz_l = 0u;
+            if (k < Kd) {
+                const uint32_t src = (wave + n_waves - (uint32_t)(((unsigned long long)k * PAIR_SPREAD) % n_waves)) % n_waves;
+                code_l = d.route_pairs[(size_t)src * Kd + k];
+                have = k < d.pair_cnt[src] && (code_l >> 7) < d.n_routes && (code_l & 127u) < n;
+            }
+            if (have) { const uint32_t r = code_l >> 7; off_l = d.route_off[r]; sz_l = d.route_off[r + 1] - off_l; }
+            unsigned long long todo = __ballot(have);
+            while (todo) {
+                const int src_lane = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                route_pair_small(d, ctrl, sm, __shfl(off_l, src_lane, 64), __shfl(sz_l, src_lane, 64), __shfl(code_l, src_lane, 64) & 127u, t0, lane WORK_PASS);
+            }
+        }
+    }
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
     for (uint32_t q = blockIdx.x; q < n_pairs; q += gridDim.x) {
         const uint32_t code = d.route_pairs_big[q], r = code >> 7, j = code & 127u;

@@ -37,6 +37,8 @@ for step in $steps; do
     ktimes) ESIM_PMAP=0 timeout -k 10 200 python tools/kernel_times.py uk64m || exit 5
             ESIM_PMAP_REBUILD=1 timeout -k 10 200 python tools/kernel_times.py uk64m || exit 5
             ESIM_PMAP_REBUILD=4 timeout -k 10 200 python tools/kernel_times.py uk64m || exit 5 ;;
+    wavepm) ESIM_PMAP=0 ESIM_DRAW_MULT=1 ESIM_UNITS_MULT=1 timeout -k 10 300 python tools/wave_profile.py uk64m 2880 3840 2>&1 | grep -E "draw:|marks" | cut -c1-330
+            ESIM_PMAP_REBUILD=4 ESIM_DRAW_MULT=1 ESIM_UNITS_MULT=1 timeout -k 10 300 python tools/wave_profile.py uk64m 2880 3840 2>&1 | grep -E "draw:|marks" | cut -c1-330 ;;
     *) echo "unknown step $step"; exit 9 ;;
   esac
 done
