@@ -854,7 +854,7 @@ void enqueue_chunk_front(esim_ctx_impl *c)
         kd_mark(c, ESIM_CK_DRAW);
         hipLaunchKernelGGL(k_chunk_draw<true>, dim3(c->grid_chunk * c->draw_mult), dim3(TPB), 0, c->stream, d, SUBQ);
         kd_mark(c, ESIM_CK_UNITS);
-        hipLaunchKernelGGL(k_chunk_units<true>, dim3(c->grid_chunk * c->draw_mult), dim3(TPB), 0, c->stream, d);     // (the same grid as k_chunk_draw: it deals that kernel's route pairs out)
+        hipLaunchKernelGGL(k_chunk_units<true>, dim3(c->grid_chunk * c->units_mult), dim3(TPB), 0, c->stream, d);
         return;
     }
     c->map_valid = false;

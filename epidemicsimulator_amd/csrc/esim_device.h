@@ -288,7 +288,7 @@ struct Dev {
 #define HOT_UNITS 64u              // [SUBQ] deferred units, by producing wavefront & 63
 #define HOT_BIGPAIRS 128u          // (route, bus step) pairs of routes with more than 64 riders
 #define HOT_BIG 129u               // [SUBQ] slots listed for k_chunk_fold, by listing wavefront & 63
-#define HOT_PAIRMAX 193u           // [SUBQ] persistent map: the most (route, bus step) pairs a wavefront of k_chunk_draw registered, by wavefront & 63
+#define HOT_RPAIRS 193u            // [SUBQ] persistent map: (route of <= 64 riders, bus step) pairs k_chunk_draw registered for k_chunk_units, by wavefront & 63
 #define HOT_PREV_NEWEXP 257u       // [SUBQ] copy of HOT_NEWEXP of the chunk whose log entries k_chunk_scatter is writing
 #define HOT_RESET 257u             // counters k_decide zeroes for a new chunk
 #define HOT_COUNT 321u

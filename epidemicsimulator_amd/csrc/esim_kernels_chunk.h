@@ -1803,7 +1803,6 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
     if (lane == 0) ws.rounds = 0u;
 #endif
     uint32_t pst[5] = { 0u, 0u, 0u, 0u, 0u };
-    uint32_t my_pairs = 0u;                                                   // (persistent map: (route, bus step) pairs this wavefront registered)
     const uint32_t pt1 = PROF_NOW();
     // (1) buildings and school rooms: one wavefront per item
     for (uint32_t v = d_lo; v < d_hi; ++v) {
@@ -1828,15 +1827,19 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
                 if (sz <= 64u) {
                     // (registered for k_chunk_units, which deals the pairs of all wavefronts out evenly -- ranked right here they
                     // made the slowest wavefront twice the median --; a stretch that is full: ranked here after all)
-                    const uint32_t Kd = (uint32_t)(2ull * d.items_cap / n_waves);
-                    uint32_t *list = d.route_pairs + (size_t)wave * Kd;
-                    for (unsigned long long m = m_lo; m; m &= m - 1ull) {
+                    const uint32_t np = (uint32_t)__popcll(m_lo) + (uint32_t)__popc(m_hi), rp_cap = 2u * d.items_cap / SUBQ, qr = wave & (SUBQ - 1u);
+                    uint32_t at = 0u;
+                    if (lane == 0) at = atomicAdd(&d.hot[(HOT_RPAIRS + qr) * HOT_STRIDE], np);      // (one reservation per route item, 64 lists)
+                    at = FX(at, 0);
+                    uint32_t *list = d.route_pairs + (size_t)qr * rp_cap;
+                    uint32_t i = 0u;
+                    for (unsigned long long m = m_lo; m; m &= m - 1ull, ++i) {
                         const uint32_t j = (uint32_t)__builtin_ctzll(m);
-                        if (my_pairs < Kd) { if (lane == 0) list[my_pairs] = (r << 7) | j; ++my_pairs; } else route_pair_small(d, ctrl, sm, it.a_lo, sz, j, t0, lane WORK_PASS);
+                        if (at + i < rp_cap) { if (lane == 0) list[at + i] = (r << 7) | j; } else route_pair_small(d, ctrl, sm, it.a_lo, sz, j, t0, lane WORK_PASS);
                     }
-                    for (uint32_t m = m_hi; m; m &= m - 1u) {
+                    for (uint32_t m = m_hi; m; m &= m - 1u, ++i) {
                         const uint32_t j = 64u + (uint32_t)__builtin_ctz(m);
-                        if (my_pairs < Kd) { if (lane == 0) list[my_pairs] = (r << 7) | j; ++my_pairs; } else route_pair_small(d, ctrl, sm, it.a_lo, sz, j, t0, lane WORK_PASS);
+                        if (at + i < rp_cap) { if (lane == 0) list[at + i] = (r << 7) | j; } else route_pair_small(d, ctrl, sm, it.a_lo, sz, j, t0, lane WORK_PASS);
                     }
                 } else {
                     const uint32_t np = (uint32_t)__popcll(m_lo) + (uint32_t)__popc(m_hi);
@@ -1911,7 +1914,6 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
             route_pair_small(d, ctrl, sm, off, sz, code & 127u, t0, lane WORK_PASS);
         }
     }
-    if (PM && lane == 0) { d.pair_cnt[wave] = my_pairs; if (my_pairs) atomicMax(&d.hot[(HOT_PAIRMAX + (wave & (SUBQ - 1u))) * HOT_STRIDE], my_pairs); }
     WORK_FLUSH(d);
     const uint32_t pt3 = PROF_NOW();
 #ifndef ESIM_PROFILE_UNITS
@@ -1944,9 +1946,9 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
     const uint32_t n_units = step ? min(ld(&d.hot[(HOT_UNITS + qr) * HOT_STRIDE]), d.unit_qcap) : 0u;
     const uint32_t n_pairs = min(ld(&d.hot[HOT_BIGPAIRS * HOT_STRIDE]), 2u * d.items_cap);
     // (persistent map: the pairs of routes of <= 64 riders that k_chunk_draw registered are dealt out here, see below)
-    uint32_t pair_max = 0u;
-    if (PM) { pair_max = ld(&d.hot[(HOT_PAIRMAX + lane) * HOT_STRIDE]); for (int o = 32; o > 0; o >>= 1) pair_max = max(pair_max, __shfl_xor(pair_max, o, 64)); }
-    if (__syncthreads_or(first < n_units) == 0 && n_pairs == 0u && pair_max == 0u) return;
+    const uint32_t rp_cap = 2u * d.items_cap / SUBQ;
+    const uint32_t n_rp = (PM && step) ? min(ld(&d.hot[(HOT_RPAIRS + qr) * HOT_STRIDE]), rp_cap) : 0u;
+    if (__syncthreads_or(first < n_units || first < n_rp) == 0 && n_pairs == 0u) return;
     for (uint32_t i = threadIdx.x; i < n; i += TPB) sm.dec[i] = d.dec[i];
     for (uint32_t i = threadIdx.x; i < 512u; i += TPB) sm.thr[i] = d.thr[i];
     __syncthreads();
@@ -2013,26 +2015,15 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
 #endif
     (void)pu0; (void)pu1; (void)pu2; (void)pu_n; (void)pu_max; (void)pu_it;
     if (PM) {
-        // Wavefront w of k_chunk_draw (same grid) left pair_cnt[w] pairs in its stretch of Kd places; its k-th pair goes to wavefront
-        // (w + k * PAIR_SPREAD) mod n_waves: lane l looks at the stretch it may have been dealt pair k0 + l from, and the wavefront
-        // takes the pairs that exist one by one -- up to the most pairs any wavefront registered.
-        const uint32_t Kd = (uint32_t)(2ull * d.items_cap / n_waves);
-        for (uint32_t k0 = 0; k0 < min(pair_max, Kd); k0 += 64u) {
-            const uint32_t k = k0 + lane;
-            bool have = false;
-            uint32_t code_l = 0u, off_l = 0u, sz_l = 0u;
-            if (k < Kd) {
-                const uint32_t src = (wave + n_waves - (uint32_t)(((unsigned long long)k * PAIR_SPREAD) % n_waves)) % n_waves;
-                code_l = d.route_pairs[(size_t)src * Kd + k];
-                have = k < d.pair_cnt[src] && (code_l >> 7) < d.n_routes && (code_l & 127u) < n;
-            }
-            if (have) { const uint32_t r = code_l >> 7; off_l = d.route_off[r]; sz_l = d.route_off[r + 1] - off_l; }
-            unsigned long long todo = __ballot(have);
-            while (todo) {
-                const int src_lane = __ffsll((long long)todo) - 1;
-                todo &= todo - 1ull;
-                route_pair_small(d, ctrl, sm, __shfl(off_l, src_lane, 64), __shfl(sz_l, src_lane, 64), __shfl(code_l, src_lane, 64) & 127u, t0, lane WORK_PASS);
-            }
+        // list `wave & 63` of the (route, bus step) pairs k_chunk_draw registered, every (n_waves / 64)-th entry of it; the next
+        // pair's route is looked up while this one is ranked
+        const uint32_t *list = d.route_pairs + (size_t)qr * rp_cap;
+        uint32_t code = first < n_rp ? list[first] : 0u, off = 0u, sz = 0u;
+        if (first < n_rp && (code >> 7) < d.n_routes) { off = d.route_off[code >> 7]; sz = d.route_off[(code >> 7) + 1u] - off; }
+        for (uint32_t q = first; q < n_rp; q += step) {
+            const uint32_t c_code = code, c_off = off, c_sz = sz;
+            if (q + step < n_rp) { code = list[q + step]; if ((code >> 7) < d.n_routes) { off = d.route_off[code >> 7]; sz = d.route_off[(code >> 7) + 1u] - off; } else sz = 0u; }
+            if ((c_code >> 7) < d.n_routes && (c_code & 127u) < n && c_sz <= 64u) route_pair_small(d, ctrl, sm, c_off, c_sz, c_code & 127u, t0, lane WORK_PASS);
         }
     }
     const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
