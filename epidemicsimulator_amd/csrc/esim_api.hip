@@ -54,7 +54,7 @@ struct esim_ctx_impl {
     uint32_t grid_chunk = 1024;
     // persistent item map (unsharded contexts): the host's view of it -- valid as long as nothing but map-maintaining chunk passes
     // has been enqueued since it was (re)built; a rebuild every pmap_rebuild_every chunks sheds the items of the recovered
-    bool pmap = true, map_valid = false, pmap_used = false;
+    bool pmap = false, map_valid = false, pmap_used = false;      // (off by default: measured slower than the per-chunk rebuild)
     uint32_t pmap_since_rebuild = 0, pmap_rebuild_every = 4;
     uint32_t draw_mult = 4, units_mult = 4;   // k_chunk_draw / k_chunk_units run this many times the marks grid: more, shorter wavefronts than the chip holds at once
     bool pipeline = true;              // run chunks of steps as one kernel per step while no vaccination programme runs
@@ -834,10 +834,16 @@ void kd_resolve(esim_ctx_impl *c)
 // marks -> fold -> draw -> units of one chunk: on the persistent item map (unsharded contexts; k_map_enter only enters who turns
 // Infected in the chunk, after a k_map_clear everybody who is Infected in it) or with the map rebuilt and torn down per chunk
 // (sharded contexts, ESIM_PMAP=0).
+// A chunk with few Infected is nothing but the latency of its kernels: those run on 64 workgroups instead of 1024 then (measured
+// on york, whose chunks are all of that kind: 3.56 instead of 4.0 ms for the 5000 steps).  The choice follows what the last
+// read-back showed, so bursts are kept short while it is in force (the epidemic may double within a hundred steps).
+bool small_chunk(const esim_ctx_impl *c) { return c->last_chunk_pairs < 4096u && c->grid_chunk > 64u && !std::getenv("ESIM_GRID_CHUNK"); }
+
 void enqueue_chunk_front(esim_ctx_impl *c)
 {
     Dev &d = c->d;
     const bool pm = c->pmap && d.world == 1u;
+    const uint32_t g = small_chunk(c) ? 64u : c->grid_chunk, g_draw = small_chunk(c) ? 64u : c->grid_chunk * c->draw_mult, g_units = small_chunk(c) ? 64u : c->grid_chunk * c->units_mult;
     if (pm) {
         if (!c->map_valid || c->pmap_since_rebuild >= c->pmap_rebuild_every) {
             kd_mark(c, ESIM_CK_MAP_CLEAR);
@@ -848,24 +854,24 @@ void enqueue_chunk_front(esim_ctx_impl *c)
         }
         c->map_valid = true; c->pmap_used = true; c->pmap_since_rebuild++;
         kd_mark(c, ESIM_CK_MARKS);
-        hipLaunchKernelGGL(k_map_enter, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+        hipLaunchKernelGGL(k_map_enter, dim3(g), dim3(TPB), 0, c->stream, d);
         kd_mark(c, ESIM_CK_FOLD);
-        hipLaunchKernelGGL(k_chunk_fold<true>, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+        hipLaunchKernelGGL(k_chunk_fold<true>, dim3(g), dim3(TPB), 0, c->stream, d);
         kd_mark(c, ESIM_CK_DRAW);
-        hipLaunchKernelGGL(k_chunk_draw<true>, dim3(c->grid_chunk * c->draw_mult), dim3(TPB), 0, c->stream, d, SUBQ);
+        hipLaunchKernelGGL(k_chunk_draw<true>, dim3(g_draw), dim3(TPB), 0, c->stream, d, SUBQ);
         kd_mark(c, ESIM_CK_UNITS);
-        hipLaunchKernelGGL(k_chunk_units<true>, dim3(c->grid_chunk * c->units_mult), dim3(TPB), 0, c->stream, d);
+        hipLaunchKernelGGL(k_chunk_units<true>, dim3(g_units), dim3(TPB), 0, c->stream, d);
         return;
     }
     c->map_valid = false;
     kd_mark(c, ESIM_CK_MARKS);
-    hipLaunchKernelGGL(k_chunk_marks, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_marks, dim3(g), dim3(TPB), 0, c->stream, d);
     kd_mark(c, ESIM_CK_FOLD);
-    hipLaunchKernelGGL(k_chunk_fold<false>, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_fold<false>, dim3(g), dim3(TPB), 0, c->stream, d);
     kd_mark(c, ESIM_CK_DRAW);
-    hipLaunchKernelGGL(k_chunk_draw<false>, dim3(c->grid_chunk * c->draw_mult), dim3(TPB), 0, c->stream, d, c->grid_chunk * (TPB / 64u));
+    hipLaunchKernelGGL(k_chunk_draw<false>, dim3(g_draw), dim3(TPB), 0, c->stream, d, g * (TPB / 64u));
     kd_mark(c, ESIM_CK_UNITS);
-    hipLaunchKernelGGL(k_chunk_units<false>, dim3(c->grid_chunk * c->units_mult), dim3(TPB), 0, c->stream, d);
+    hipLaunchKernelGGL(k_chunk_units<false>, dim3(g_units), dim3(TPB), 0, c->stream, d);
 }
 
 void enqueue_parallel_chunk(esim_ctx_impl *c, int then_next, uint32_t limit_t)
@@ -1032,7 +1038,7 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             // control block and is a no-op when the chunk cannot run time-parallel (then the steps simply do not advance,
             // which the read-back below sees, and the synchronous path further down takes over for one chunk).
             const uint32_t first = c->host_t, limit_t = first + remaining - 1u;
-            const uint32_t bursts = std::min<uint32_t>((remaining + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n, probing ? 1u : 16u);   // (the form of a chunk's book-keeping is chosen from what the last read-back showed)
+            const uint32_t bursts = std::min<uint32_t>((remaining + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n, probing ? 1u : (small_chunk(c) ? 4u : 16u));   // (the form of a chunk's book-keeping is chosen from what the last read-back showed)
             const bool tk = c->kernel_timing;
             if (tk) { if (!c->cev[0]) { (void)hipEventCreate(&c->cev[0]); (void)hipEventCreate(&c->cev[1]); } HIP_TRY(c, hipEventRecord(c->cev[0], c->stream)); }
             kd_mark(c, ESIM_CK_FUTURE);
@@ -1645,6 +1651,16 @@ extern "C" int esim_set_pipeline(esim_ctx *ctx, int enable)
     c->pipeline = enable != 0;            // 0: sequential steps only
     c->time_parallel = enable >= 2;       // 1: one kernel per step (k_pipe); 2: all steps of a chunk in one pass
     c->vax_chunks = enable >= 3;          // 3 (default): ... also while a vaccination programme runs, its vaccinations planned per chunk
+    if (enable >= 4 && !c->pmap) { c->pmap = true; c->map_valid = false; }   // 4: ... on the persistent item map (unsharded contexts)
+    if (enable < 4 && c->pmap && !std::getenv("ESIM_PMAP")) {                // back to the per-chunk map: whatever the persistent one holds is emptied first
+        if (c->pmap_used && c->uploaded) {
+            hipLaunchKernelGGL(k_map_clear, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, c->d);
+            hipLaunchKernelGGL(k_map_reset, dim3(1), dim3(64), 0, c->stream, c->d);
+            (void)hipMemsetAsync(c->d.sch_ring, 0, sizeof(uint32_t) * (size_t)(c->d.n_sch ? c->d.n_sch : 1) * 2u * SCH_RING, c->stream);
+            c->pmap_used = false;
+        }
+        c->pmap = false; c->map_valid = false;
+    }
     return ESIM_OK;
 }
 

@@ -165,7 +165,8 @@ int  esim_exchange_buffer(esim_ctx *ctx, int which /* 0 = A, 1 = B, 2 = F */, vo
  * writing the census ahead of the chunk after it into F -- and calls esim_free_collect(&done) once: done = steps the
  * burst advanced (the same on all shards).
  * esim_set_pipeline(ctx, level): 0 = sequential steps only; 1 = chunks run as one kernel per step (k_pipe);
- * 3 (default) = as 2, and chunks keep running under a vaccination programme (esim_vax_chunk_stats);
+ * 3 (default) = as 2, and chunks keep running under a vaccination programme (esim_vax_chunk_stats); 4 = as 3 on the persistent
+ * item map (a citizen is entered into the items it stands in once, when it turns Infected, instead of in every chunk; unsharded contexts);
  * 2 = additionally to 1, when the chunk's marks fit the hash map, ALL steps of a chunk are drawn in one
  * pass (a citizen's exposure step is the earliest step at which any of its draws succeeds -- one atomicMin on
  * the citizen word per successful draw).  esim_chunk_timing: device time (ms), steps and number of such chunks

@@ -31,7 +31,7 @@ def assert_same_state(sim, orc):
 # vaccination programme with the chunk's vaccinations planned ahead), time-parallel chunks until a programme starts and
 # sequential steps from there, chunks as one kernel per step, and sequential steps only with the default hand-over between the
 # persistent single-workgroup kernel and the multi-workgroup kernels, multi-workgroup kernels only, persistent kernel only
-SMALL_LIMITS = ("vax", "tp", "pipe", None, 0, 1 << 30)
+SMALL_LIMITS = ("pmap", "vax", "tp", "pipe", None, 0, 1 << 30)      # the seven execution forms
 
 
 def run_both(pop, steps, check_state_every=None, small_limits=SMALL_LIMITS, **params):
@@ -42,7 +42,9 @@ def run_both(pop, steps, check_state_every=None, small_limits=SMALL_LIMITS, **pa
 def _run_both(pop, steps, check_state_every, small_limit, **params):
     ep = _lib.default_params(**params)
     sim = Simulator(pop, ep)
-    if small_limit == "vax":
+    if small_limit == "pmap":
+        sim.set_pipeline(4)                       # ... on the persistent item map (entered once per infection, not per chunk)
+    elif small_limit == "vax":
         sim.set_pipeline(3)                       # time-parallel chunks, also under a vaccination programme (default)
     elif small_limit == "tp":
         sim.set_pipeline(2)                       # time-parallel chunks until a vaccination programme starts
@@ -110,7 +112,7 @@ def test_york_default_params_1000_steps():
 def test_york_full_5000_steps_vaccination_85():
     # BASELINE.json configs[1]: York, 5000 steps, fixed Philox seed vs CPU counts; v1.7.1's rate 85/step
     # (forms: planned chunks under the programme -- the default, level 3 --, chunks until it starts, one kernel per step, sequential)
-    run_both(Population.synthetic("york"), 5000, small_limits=("vax", "tp", "pipe", None), vaccination_rate=85, vaccination_threshold=0.003)
+    run_both(Population.synthetic("york"), 5000, small_limits=("pmap", "vax", "tp", "pipe", None), vaccination_rate=85, vaccination_threshold=0.003)
 
 
 def test_yh_census_config_1500_steps():
@@ -436,7 +438,7 @@ def test_chunk_pass_with_few_wavefronts(grid, monkeypatch):
     pop = random_population(4242 + grid, n=9000, n_areas=9, n_buildings=500, n_schools=4, rooms_per_school=6)
     params = dict(exposure_chance=0.01, seed=99173 + grid, vaccination_rate=400, vaccination_threshold=0.3, lockdown_threshold=0.15,
                   mask_pt_threshold=0.02, mask_everywhere_threshold=0.2, bus_capacity=20, exposed_time=30, infected_time=100)
-    run_both(pop, 600, check_state_every=97, small_limits=("vax", "tp"), **params)
+    run_both(pop, 600, check_state_every=97, small_limits=("pmap", "vax", "tp"), **params)
 
 
 @pytest.mark.parametrize("seed", range(6))

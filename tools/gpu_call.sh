@@ -39,6 +39,11 @@ for step in $steps; do
             ESIM_PMAP_REBUILD=4 timeout -k 10 200 python tools/kernel_times.py uk64m || exit 5 ;;
     wavepm) ESIM_PMAP=0 ESIM_DRAW_MULT=1 ESIM_UNITS_MULT=1 timeout -k 10 300 python tools/wave_profile.py uk64m 2880 3840 2>&1 | grep -E "draw:|marks" | cut -c1-330
             ESIM_PMAP_REBUILD=4 ESIM_DRAW_MULT=1 ESIM_UNITS_MULT=1 timeout -k 10 300 python tools/wave_profile.py uk64m 2880 3840 2>&1 | grep -E "draw:|marks" | cut -c1-330 ;;
+    counts) ESIM_PMAP=0 timeout -k 10 300 python tools/work_counts.py cnt_old uk64m | cut -c1-900 || exit 5
+            timeout -k 10 300 python tools/work_counts.py cnt_pm uk64m | cut -c1-900 || exit 5 ;;
+    waveu) ESIM_PMAP=0 timeout -k 10 300 python tools/wave_profile_units.py uk64m 2880 3840 2>&1 | cut -c1-330
+           timeout -k 10 300 python tools/wave_profile_units.py uk64m 2880 3840 2>&1 | cut -c1-330 ;;
+    presets) for p in york syn3m5 yh_census uk64m; do timeout -k 10 200 python tools/run_preset.py $p | grep us/step | cut -c1-150 || exit 5; done ;;
     *) echo "unknown step $step"; exit 9 ;;
   esac
 done
