@@ -56,6 +56,7 @@ struct esim_ctx_impl {
     // has been enqueued since it was (re)built; a rebuild every pmap_rebuild_every chunks sheds the items of the recovered
     bool pmap = false, map_valid = false, pmap_used = false;      // (off by default: measured slower than the per-chunk rebuild)
     uint32_t pmap_since_rebuild = 0, pmap_rebuild_every = 4;
+    uint32_t small_grid = 64, small_mult = 4;  // chunks with few Infected: workgroups of the marks / fold kernels, multiplier of the draw kernels (0: off)
     uint32_t draw_mult = 4, units_mult = 4;   // k_chunk_draw / k_chunk_units run this many times the marks grid: more, shorter wavefronts than the chip holds at once
     bool pipeline = true;              // run chunks of steps as one kernel per step while no vaccination programme runs
     bool vax_chunks = true;            // time-parallel chunks also under a vaccination programme (their vaccinations planned ahead, k_chunk_vax)
@@ -573,6 +574,8 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     c->grid_expose = 1024;
     if (const char *e = std::getenv("ESIM_GRID_INFECTED")) c->grid_infected = (uint32_t)std::max(1, std::atoi(e));   // tuning knobs
     if (const char *e = std::getenv("ESIM_GRID_CHUNK")) c->grid_chunk = (uint32_t)std::min((int)(CHUNK_WAVES_MAX * 64u / TPB), std::max(16, std::atoi(e) / 16 * 16));   // whole groups of 64 wavefronts
+    if (const char *e = std::getenv("ESIM_SMALL_GRID")) c->small_grid = (uint32_t)std::max(0, std::atoi(e) / 16 * 16);
+    if (const char *e = std::getenv("ESIM_SMALL_MULT")) c->small_mult = (uint32_t)std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("ESIM_PMAP")) c->pmap = std::atoi(e) != 0;
     if (const char *e = std::getenv("ESIM_PMAP_REBUILD")) c->pmap_rebuild_every = (uint32_t)std::max(1, std::atoi(e));
     if (const char *e = std::getenv("ESIM_DRAW_MULT")) c->draw_mult = (uint32_t)std::min(4, std::max(1, std::atoi(e)));      // (16 384 wavefronts at most: Dev::pair_cnt)
@@ -837,13 +840,13 @@ void kd_resolve(esim_ctx_impl *c)
 // A chunk with few Infected is nothing but the latency of its kernels: those run on 64 workgroups instead of 1024 then (measured
 // on york, whose chunks are all of that kind: 3.56 instead of 4.0 ms for the 5000 steps).  The choice follows what the last
 // read-back showed, so bursts are kept short while it is in force (the epidemic may double within a hundred steps).
-bool small_chunk(const esim_ctx_impl *c) { return c->last_chunk_pairs < 4096u && c->grid_chunk > 64u && !std::getenv("ESIM_GRID_CHUNK"); }
+bool small_chunk(const esim_ctx_impl *c) { return c->small_grid && c->last_chunk_pairs < 4096u && c->grid_chunk > c->small_grid && !std::getenv("ESIM_GRID_CHUNK"); }
 
 void enqueue_chunk_front(esim_ctx_impl *c)
 {
     Dev &d = c->d;
     const bool pm = c->pmap && d.world == 1u;
-    const uint32_t g = small_chunk(c) ? 64u : c->grid_chunk, g_draw = small_chunk(c) ? 64u : c->grid_chunk * c->draw_mult, g_units = small_chunk(c) ? 64u : c->grid_chunk * c->units_mult;
+    const uint32_t g = small_chunk(c) ? c->small_grid : c->grid_chunk, g_draw = g * (small_chunk(c) ? c->small_mult : c->draw_mult), g_units = g * (small_chunk(c) ? c->small_mult : c->units_mult);
     if (pm) {
         if (!c->map_valid || c->pmap_since_rebuild >= c->pmap_rebuild_every) {
             kd_mark(c, ESIM_CK_MAP_CLEAR);

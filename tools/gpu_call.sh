@@ -44,6 +44,8 @@ for step in $steps; do
     waveu) ESIM_PMAP=0 timeout -k 10 300 python tools/wave_profile_units.py uk64m 2880 3840 2>&1 | cut -c1-330
            timeout -k 10 300 python tools/wave_profile_units.py uk64m 2880 3840 2>&1 | cut -c1-330 ;;
     presets) for p in york syn3m5 yh_census uk64m; do timeout -k 10 200 python tools/run_preset.py $p | grep us/step | cut -c1-150 || exit 5; done ;;
+    smallgrid) for v in "0 1" "64 1" "64 4" "128 4" "256 1" "32 8"; do set -- $v; for i in 1 2; do echo -n "small grid $1 mult $2: "; ESIM_SMALL_GRID=$1 ESIM_SMALL_MULT=$2 timeout -k 10 200 python tools/run_preset.py york | grep us/step | cut -c1-110 || exit 5; done; done
+            for v in "0 1" "64 4"; do set -- $v; echo -n "bench20 small grid $1 mult $2: "; ESIM_SMALL_GRID=$1 ESIM_SMALL_MULT=$2 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-extra-runs --cpu-seconds 0 | python -c "import sys,json; d=json.loads(sys.stdin.read()); t=d['config']['timed_region']; print(t['wall_us_per_step']*20, t['chunk_passes_device_ms']*1e3)" || exit 6; done ;;
     *) echo "unknown step $step"; exit 9 ;;
   esac
 done
