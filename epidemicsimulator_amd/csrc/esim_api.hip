@@ -70,6 +70,8 @@ struct esim_ctx_impl {
     uint32_t *xr = nullptr; size_t xr_n = 0;      // records exchange (sharded chunks)
     uint64_t shard_chunk_steps = 0, shard_step_steps = 0;
     uint64_t comm_calls = 0;
+    bool xs_a2a = true;                 // the commuter exchange as an all-to-all of owner-addressed segments (ESIM_XS_MODE=gather: all-gather)
+    uint32_t *xs_out = nullptr, *shared_mask = nullptr;
     // pinned host mirrors: the control block and the records of the call in flight come back with ONE stream wait (two blocking
     // copies into pageable memory cost more than a small chunk's kernels)
     Ctrl *pin_ctrl = nullptr;
@@ -537,8 +539,8 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if ((rc = dev_upload(c, &d.shared_of_room, of_r.data(), of_r.size()))) return rc;
         if ((rc = dev_alloc(c, &d.xv, XV_HEADER + (size_t)FREE_MAX * (PLAN_W / 32u)))) return rc;
         if ((rc = dev_alloc(c, &d.xc, FREE_MAX + 2u))) return rc;
-        if ((rc = dev_alloc(c, &d.xe, 2))) return rc;
-        HIP_TRY(c, hipMemset(d.xe, 0, sizeof(uint32_t) * 2u));
+        if ((rc = dev_alloc(c, &d.xe, XE_WORDS))) return rc;
+        HIP_TRY(c, hipMemset(d.xe, 0, sizeof(uint32_t) * XE_WORDS));
         HIP_TRY(c, hipMemset(d.xv, 0, sizeof(uint32_t) * (XV_HEADER + (size_t)FREE_MAX * (PLAN_W / 32u))));
         HIP_TRY(c, hipMemset(d.xc, 0, sizeof(uint32_t) * (FREE_MAX + 2u)));
         d.rank = 0; d.world = 1; d.xs = nullptr;
@@ -1253,6 +1255,41 @@ int exchange_gather(esim_ctx_impl *c, int which, uint32_t *buf, size_t per_rank)
 
 int wait_stream(esim_ctx_impl *c);
 
+// All-to-all: rank s sends the `seg` words at out + d * seg to rank d, and receives rank r's words for it at in + r * seg.  RCCL:
+// one group of ncclSend / ncclRecv pairs on the context's stream (every pair of shards talks over its own xGMI link).  A caller's
+// transport only has a SUM all-reduce: the ranks' rows of the [sender][receiver] matrix are summed and each picks its column.
+int exchange_alltoall(esim_ctx_impl *c, int which, const uint32_t *out, uint32_t *in, size_t seg)
+{
+    const int W = c->comm_world, me = c->comm_rank;
+    if (W <= 1) return ESIM_OK;
+    c->comm_calls++;
+    if (c->nccl) {
+        ncclResult_t r = rccl().GroupStart();
+        for (int p = 0; p < W && r == ncclSuccess; ++p) {
+            if (p == me) continue;
+            r = rccl().Send(out + (size_t)p * seg, seg, ncclUint32, p, c->nccl, c->stream);
+            if (r == ncclSuccess) r = rccl().Recv(in + (size_t)p * seg, seg, ncclUint32, p, c->nccl, c->stream);
+        }
+        const ncclResult_t e = rccl().GroupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) return fail(c, ESIM_ENODEVICE, std::string("ncclSend/ncclRecv: ") + rccl().GetErrorString(r));
+        return ESIM_OK;
+    }
+    if (c->comm_fn) {
+        const size_t n = (size_t)W * W * seg;
+        c->comm_stage.assign(n, 0u);
+        HIP_TRY(c, hipMemcpyAsync(c->comm_stage.data() + (size_t)me * W * seg, out, sizeof(uint32_t) * (size_t)W * seg, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < seg; ++i) c->comm_stage[((size_t)me * W + me) * seg + i] = 0u;          // (nothing goes to oneself)
+        if (c->comm_fn(c->comm_user, which, c->comm_stage.data(), n) != 0) return fail(c, ESIM_ENODEVICE, "the caller's all-reduce failed");
+        for (int p = 0; p < W; ++p)
+            if (p != me) HIP_TRY(c, hipMemcpyAsync(in + (size_t)p * seg, c->comm_stage.data() + ((size_t)p * W + me) * seg, sizeof(uint32_t) * seg, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return ESIM_OK;
+    }
+    return fail(c, ESIM_ESTATE, "sharded run without a communicator (esim_comm_init_rccl / esim_comm_init_callback)");
+}
+
 // what the exchange of sharded chunks needs once the number of ranks is known; and the ranks' shards are checked against each
 // other -- one world (n_citizens_global, shared tables of the same size), rank r holding the r-th stretch of the global
 // citizen ids -- with one small all-reduce: a communicator over shards that do not belong together would run without an
@@ -1265,6 +1302,10 @@ int comm_buffers(esim_ctx_impl *c)
     int rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (d.xs) { dev_free(c, d.xs); d.xs = nullptr; }
+    if (c->xs_out) { dev_free(c, c->xs_out); c->xs_out = nullptr; }
+    if (c->shared_mask) { dev_free(c, c->shared_mask); c->shared_mask = nullptr; }
+    d.xs_out = nullptr; d.shared_mask = nullptr;
+    if (const char *e = std::getenv("ESIM_XS_MODE")) c->xs_a2a = std::string(e) != "gather";
     if (c->xr) { dev_free(c, c->xr); c->xr = nullptr; c->xr_n = 0; }
     d.rank = (uint32_t)c->comm_rank; d.world = (uint32_t)c->comm_world;
     const size_t n = (size_t)d.world * (1u + 3u * (size_t)XS_CAP_MAX);
@@ -1297,6 +1338,20 @@ int comm_buffers(esim_ctx_impl *c)
         next += q[1];
     }
     if (next != d.n_global) return fail(c, ESIM_EINVAL, "esim_comm_init: the ranks' shards do not add up to n_citizens_global (world size differs from the number of shards)");
+    if (c->xs_a2a && W > 1) {
+        // which shards have members in each shared building: every shard sets its own bit where it has, the bits are summed
+        if ((rc = dev_alloc(c, &c->shared_mask, (size_t)d.n_shared_bld + 1u))) return rc;
+        std::vector<uint32_t> bits((size_t)d.n_shared_bld + 1u, 0u);
+        std::vector<int32_t> local((size_t)d.n_shared_bld + 1u, -1);
+        if (d.n_shared_bld) HIP_TRY(c, hipMemcpy(local.data(), d.shared_bld, sizeof(int32_t) * d.n_shared_bld, hipMemcpyDeviceToHost));
+        for (uint32_t k = 0; k < d.n_shared_bld; ++k) bits[k] = local[k] >= 0 ? 1u << d.rank : 0u;
+        HIP_TRY(c, hipMemcpy(c->shared_mask, bits.data(), sizeof(uint32_t) * bits.size(), hipMemcpyHostToDevice));
+        if ((rc = exchange_buf(c, 9, c->shared_mask, bits.size()))) return rc;
+        if ((rc = wait_stream(c))) return rc;
+        if ((rc = dev_alloc(c, &c->xs_out, n))) return rc;
+        HIP_TRY(c, hipMemset(c->xs_out, 0, sizeof(uint32_t) * n));
+        d.xs_out = c->xs_out; d.shared_mask = c->shared_mask;
+    }
     return ESIM_OK;
 }
 
@@ -1341,7 +1396,7 @@ int sync_status(esim_ctx_impl *c, bool ex, Ctrl *h)
     Dev &d = c->d;
     int rc;
     hipLaunchKernelGGL(k_status_pack, dim3(1), dim3(64), 0, c->stream, d);
-    if (ex && (rc = exchange_buf(c, 7, d.xe, 2))) return rc;
+    if (ex && (rc = exchange_buf(c, 7, d.xe, XE_WORDS))) return rc;
     hipLaunchKernelGGL(k_status_unpack, dim3(1), dim3(64), 0, c->stream, d);
     HIP_TRY(c, hipMemcpyAsync(h, d.ctrl, sizeof *h, hipMemcpyDeviceToHost, c->stream));
     if ((rc = wait_stream(c))) return rc;
@@ -1442,11 +1497,19 @@ int enqueue_sharded_chunk(esim_ctx_impl *c, uint32_t limit_t, bool vax)
         hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 0);
     }
     const size_t seg = 1u + 3u * (size_t)d.xs_cap;
-    HIP_TRY(c, hipMemsetAsync(d.xs + (size_t)d.rank * seg, 0, sizeof(uint32_t), c->stream));
-    if (c->comm_fn)          // (a caller's transport sums the whole buffer: the other ranks' segments must be zero)
-        for (uint32_t r = 0; r < d.world; ++r) if (r != d.rank) HIP_TRY(c, hipMemsetAsync(d.xs + (size_t)r * seg, 0, sizeof(uint32_t) * seg, c->stream));
-    hipLaunchKernelGGL(k_shared_pack, dim3(256), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
-    if ((rc = exchange_gather(c, 4, d.xs, seg))) return rc;
+    if (d.xs_out) {
+        // all-to-all: a record goes to the shards that have members in its building; segments of the same size
+        // between every pair of shards (their need is exchanged with the status, so they grow alike everywhere)
+        for (uint32_t r = 0; r < d.world; ++r) HIP_TRY(c, hipMemsetAsync(d.xs_out + (size_t)r * seg, 0, sizeof(uint32_t), c->stream));
+        hipLaunchKernelGGL(k_shared_pack, dim3(256), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+        if ((rc = exchange_alltoall(c, 4, d.xs_out, d.xs, seg))) return rc;
+    } else {
+        HIP_TRY(c, hipMemsetAsync(d.xs + (size_t)d.rank * seg, 0, sizeof(uint32_t), c->stream));
+        if (c->comm_fn)          // (a caller's transport sums the whole buffer: the other ranks' segments must be zero)
+            for (uint32_t r = 0; r < d.world; ++r) if (r != d.rank) HIP_TRY(c, hipMemsetAsync(d.xs + (size_t)r * seg, 0, sizeof(uint32_t) * seg, c->stream));
+        hipLaunchKernelGGL(k_shared_pack, dim3(256), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+        if ((rc = exchange_gather(c, 4, d.xs, seg))) return rc;
+    }
     hipLaunchKernelGGL(k_shard_prep, dim3(1), dim3(128), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
     if ((rc = exchange(c, 2))) return rc;
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 1);
@@ -1527,11 +1590,11 @@ extern "C" int esim_run_sharded(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_don
             c->shard_chunk_steps += done;
             // the commuter segment follows the need (the same on every rank: the counts were gathered)
             const uint32_t cap_before = d.xs_cap;
-            while (d.xs_cap < XS_CAP_MAX && 2u * h.xs_need > d.xs_cap) d.xs_cap *= 2u;
+            while (d.xs_cap < XS_CAP_MAX && 2u * h.xs_need_all > d.xs_cap) d.xs_cap *= 2u;     // (xs_need_all: the maximum over the shards, from the status exchange)
             if (done) { local_ranges.emplace_back(t_first, done); stall = 0; continue; }
             if (std::getenv("ESIM_DEBUG"))
                 std::fprintf(stderr, "[esim] rank %d: sharded chunk without progress at t=%u: chunk_ok=%u parallel=%u vax_chunk=%u vax_fail=%u cannot=%u xs_need=%u xs_cap=%u pairs=%u\n",
-                             c->comm_rank, h.t, h.chunk_ok, h.chunk_parallel, h.vax_chunk, h.vax_fail, 0u, h.xs_need, cap_before, h.chunk_pairs);
+                             c->comm_rank, h.t, h.chunk_ok, h.chunk_parallel, h.vax_chunk, h.vax_fail, 0u, h.xs_need_all, cap_before, h.chunk_pairs);
             if (d.xs_cap != cap_before) continue;                        // the segment was too short: again with the longer one
             stall = std::min<uint32_t>(stall + 1u, 8u);
         }

@@ -105,7 +105,8 @@ struct Ctrl {
     uint32_t prev_n, prev_n_eff, prev_vax; // the chunk k_chunk_scatter is finishing: its length, the steps committed, whether it was planned
     uint32_t vax_cuts;          // diagnostics: chunks that were cut short
     uint32_t vax_planned, prev_planned; // steps the plan of the chunk in preparation / being finished covers (>= the chunk's length)
-    uint32_t xs_need;           // sharded chunks: the most commuter records any shard wanted to send for the chunk last prepared
+    uint32_t xs_need;           // sharded chunks: the most commuter records THIS shard saw in one segment of the chunk last prepared
+    uint32_t xs_need_all;       // ... any shard did (summed by slot in the status exchange: the segments grow by the same factor everywhere)
     uint32_t vax_fail;          // sharded plans: steps whose candidates beyond the exchanged window would have been needed (plan void)
     // persistent item map: valid for a chunk that starts at step map_t -- every form that advances the clock
     // without maintaining the map (sequential steps, k_pipe chunks, a restore) leaves map_t behind and so invalidates it
@@ -125,6 +126,7 @@ struct Ctrl {
 // code c (at most 31 shards).  Every shard decodes the lowest code present, i.e. the same one.
 #define ERR_FIELD(code) ((code) ? 1u << (5u * (((code) < 1u || (code) > 6u ? 6u : (code)) - 1u)) : 0u)
 #define ERR_MAX_WORLD 31u
+#define XE_WORDS (2u + ERR_MAX_WORLD)
 static inline __host__ __device__ uint32_t err_decode(uint32_t word)
 {
     for (uint32_t c = 1u; c <= 6u; ++c) if ((word >> (5u * (c - 1u))) & 31u) return c;
@@ -255,8 +257,12 @@ struct Dev {
     uint32_t *xv;                       // [XV_HEADER + FREE_MAX * PLAN_W / 32] liveness of every step's first PLAN_W vaccination candidates
     uint32_t *xs;                       // [world][1 + 3 * xs_cap] Infected commuters to shared buildings: (citizen word, shared building, shared room | -1)
     uint32_t xs_cap;                    // records per shard in this chunk's exchange
+    // the commuter exchange as an all-to-all: a record goes to the shards that have members in its building, and to no other
+    uint32_t *xs_out;                   // [world][1 + 3 * xs_cap] what this shard sends to each of the others (nullptr: the all-gather form)
+    const uint32_t *shared_mask;        // [n_shared_bld] bit r: shard r has members in the shared building (summed at set-up)
     uint32_t *xc;                       // [FREE_MAX + 2] steps of the chunk with a cut (k_chunk_count)
-    uint32_t *xe;                       // [2] status exchange: [0] error fields (ERR_FIELD), [1] shards that are finished
+    uint32_t *xe;                       // [XE_WORDS] status exchange: [0] error fields (ERR_FIELD), [1] shards that are finished, [2 + r] the most
+                                        // commuter records shard r wanted to send to one destination in the chunk last prepared
     const int32_t *shared_of_bld, *shared_of_room;   // [n_bld], [n_room]: index into the shared tables, -1 when not shared
 #ifdef ESIM_COUNT_WORK
     unsigned long long *work_cnt;       // counting build only: [WK_N] what the chunk pass worked on (tools/work_counts.py)

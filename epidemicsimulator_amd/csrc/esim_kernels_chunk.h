@@ -442,6 +442,20 @@ __global__ __launch_bounds__(TPB) void k_shared_pack(Dev d, uint32_t max_ahead, 
         }
         const unsigned long long m = __ballot(send);
         if (!m) continue;
+        if (d.xs_out) {
+            // all-to-all: the record goes into the segment of every OTHER shard that has members in the building
+            const uint32_t to = send ? d.shared_mask[sb] & ~(1u << d.rank) : 0u;
+            for (uint32_t r = 0; r < d.world; ++r) {
+                const unsigned long long mr = __ballot((to >> r) & 1u);
+                if (!mr) continue;
+                uint32_t *out = d.xs_out + (size_t)r * (1u + 3u * d.xs_cap);
+                uint32_t pos = 0u;
+                if (lane == 0) pos = atomicAdd(&out[0], (uint32_t)__popcll(mr));
+                pos = __shfl(pos, 0, 64) + (uint32_t)__popcll(mr & ((1ull << lane) - 1ull));
+                if (((to >> r) & 1u) && pos < d.xs_cap) { out[1u + 3u * pos] = w; out[2u + 3u * pos] = sb; out[3u + 3u * pos] = sr; }
+            }
+            continue;
+        }
         uint32_t pos = 0u;
         if (lane == 0) pos = atomicAdd(&seg[0], (uint32_t)__popcll(m));       // one atomic per wavefront
         pos = __shfl(pos, 0, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -464,8 +478,13 @@ __global__ __launch_bounds__(128) void k_shard_prep(Dev d, uint32_t max_ahead, u
         if (cnt > d.xs_cap) overflow = true;
         if (r != d.rank) n_remote += min(cnt, d.xs_cap);
     }
+    // (what this shard saw: the segments it received -- and, in the all-to-all form, those it sent; the status exchange takes the
+    // maximum over the shards, so that the segments grow alike everywhere)
     ctrl->xs_need = 0u;
-    for (uint32_t r = 0; r < d.world; ++r) ctrl->xs_need = max(ctrl->xs_need, d.xs[(size_t)r * (1u + 3u * d.xs_cap)]);
+    for (uint32_t r = 0; r < d.world; ++r) {
+        if (r != d.rank || !d.xs_out) ctrl->xs_need = max(ctrl->xs_need, d.xs[(size_t)r * (1u + 3u * d.xs_cap)]);
+        if (d.xs_out && r != d.rank) { const uint32_t o = d.xs_out[(size_t)r * (1u + 3u * d.xs_cap)]; ctrl->xs_need = max(ctrl->xs_need, o); if (o > d.xs_cap) overflow = true; }
+    }
     // (a shard in a device-side error state makes the chunk a no-op on EVERY shard: the word is summed)
     const bool fits = d.xf[d.xf_n] == 0u && !overflow && !ctrl->error && !ctrl->finished &&
                       ((unsigned long long)ctrl->chunk_pairs + n_remote) * 4ull + 65536ull <= (unsigned long long)d.items_cap;

@@ -62,9 +62,15 @@ __global__ __launch_bounds__(TPB) void k_records_unpack(Dev d, uint32_t first, u
 __global__ __launch_bounds__(64) void k_status_pack(Dev d)
 {
     if (threadIdx.x == 0) { d.xe[0] = ERR_FIELD(d.ctrl->error); d.xe[1] = d.ctrl->finished ? 1u : 0u; }
+    if (threadIdx.x < ERR_MAX_WORLD) d.xe[2u + threadIdx.x] = threadIdx.x == d.rank ? d.ctrl->xs_need : 0u;
 }
 
 __global__ __launch_bounds__(64) void k_status_unpack(Dev d)
 {
-    if (threadIdx.x == 0) { d.ctrl->peer_error |= d.xe[0]; if (d.xe[0] && !d.ctrl->error) d.ctrl->error = err_decode(d.xe[0]); }
+    if (threadIdx.x == 0) {
+        d.ctrl->peer_error |= d.xe[0]; if (d.xe[0] && !d.ctrl->error) d.ctrl->error = err_decode(d.xe[0]);
+        uint32_t need = 0u;
+        for (uint32_t r = 0; r < ERR_MAX_WORLD; ++r) need = max(need, d.xe[2u + r]);
+        d.ctrl->xs_need_all = need;
+    }
 }

@@ -179,7 +179,7 @@ int  esim_exchange_buffer(esim_ctx *ctx, int which /* 0 = A, 1 = B, 2 = F */, vo
  * esim_comm_init_callback -- instead: the caller's own SUM all-reduce over the ranks, in place, of `n_u32` uint32 in HOST memory
  *                            at `host_ptr` (the library stages the device buffer through it with the stream drained; `which`
  *                            names the buffer: 0 A, 1 B, 2 F, 3 plan liveness, 4 commuter records, 5 cuts, 6 records, 7 status,
- *                            8 the set-up's layout check);
+ *                            8 the set-up's layout check, 9 which shards have members in each shared building);
  *                            returns 0 on success.  For transports other than RCCL and for tests with several ranks on one GPU.
  * esim_run_sharded        -- replaces the loop of Simulator::simulate (simulator.rs:114-123) for this rank's shard: n_steps
  *                            time steps, every rank calling it with the same n_steps; records of these steps hold the census

@@ -14,6 +14,7 @@
   python profiles/summarize_r03.py <tag> <dir with the passes> [--workload uk64m --steps 5000] | --calib"""
 import json
 import os
+import re
 import sqlite3
 import sys
 from collections import defaultdict
@@ -27,6 +28,13 @@ CLOCK_MAX_GHZ = 2.4
 # VALU activity per wave), so "busy" = active quad-cycles x 4 / elapsed cycles per SIMD.
 
 
+def kname(display):
+    """'void k_chunk_draw<false>(Dev, unsigned int)' -> 'k_chunk_draw' (template instances of one kernel are one kernel here)."""
+    n = display.split("(")[0].strip()
+    n = re.sub(r"<.*>$", "", n)
+    return n.split()[-1] if n else n
+
+
 def db_path(d, name):
     p = os.path.join(d, name, "%s_results.db" % name)
     return p if os.path.exists(p) else None
@@ -37,7 +45,7 @@ def durations(db):
     names = {r[0]: r[1] for r in cur.execute("select id, display_name from rocpd_info_kernel_symbol")}
     per = defaultdict(list)
     for kid, s, e in cur.execute("select kernel_id, start, end from rocpd_kernel_dispatch"):
-        per[names[kid].split("(")[0]].append((e - s) / 1e3)
+        per[kname(names[kid])].append((e - s) / 1e3)
     return per
 
 
@@ -49,7 +57,7 @@ def counters(db):
     acc = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))
     dur = defaultdict(dict)
     for name, disp, cname, val, d in cur.execute("select name, dispatch_id, counter_name, counter_value, duration from pmc_events"):
-        k = name.split("(")[0]
+        k = kname(name)
         acc[cname][k][disp] += float(val)
         dur[k][disp] = d / 1e3
     return {c: {k: list(v.values()) for k, v in per.items()} for c, per in acc.items()}, {k: list(v.values()) for k, v in dur.items()}

@@ -56,6 +56,18 @@ def test_two_shards_match_oracle():
     assert all("ok" in o for o in outs)
 
 
+def test_two_and_three_shards_all_gather_exchange_match_oracle():
+    # the commuter exchange of the chunk form is an all-to-all of owner-addressed segments by default (a record goes to the shards
+    # that have members in its building); ESIM_XS_MODE=gather keeps round 2's all-gather of every shard's records to every shard
+    # for the A/B -- same records either way
+    cfg = dict(backend="gloo", cuts="even", spec=dict(n_citizens=12000, n_areas=40, citizens_per_school=2500, n_seeds=16),
+               params=AGGRESSIVE, steps=360, chunk=120, expect=dict(vaccinated=1),
+               env_by_rank={str(r): {"ESIM_XS_MODE": "gather"} for r in range(3)})
+    assert all("ok" in o for o in launch(2, cfg))
+    cfg3 = dict(cfg, spec=dict(n_citizens=9000, n_areas=13, citizens_per_school=3000, n_seeds=16), params=dict(AGGRESSIVE, seed=9), steps=240)
+    assert all("ok" in o for o in launch(3, cfg3))
+
+
 def test_two_shards_coupled_steps_only_match_oracle():
     # the form every step can take: three device phases around two exchanges per step (pipeline level 0)
     cfg = dict(backend="gloo", cuts="even", spec=dict(n_citizens=12000, n_areas=40, citizens_per_school=2500, n_seeds=16),
