@@ -105,7 +105,7 @@ def cpu_baseline(pop, params, seconds, threads):
         steps += 8
     rsh.close()
     rec = np.concatenate(recs)
-    return {"value": sample.n_citizens * steps / spent, "unit": "citizen-timesteps/s", "cores": threads, "kind": "reference-shaped",
+    return {"value": sample.n_citizens * steps / spent, "unit": "citizen-timesteps/s", "cores": threads, "kind": "port", "shape": "reference-shaped (area-parallel array-of-structs citizens, per-area hash maps, mutex-guarded lookup: oracle/esim_refshape.cpp)",
             "sample": "Output Areas [0, %d) of the same world (%d citizens, a band of the map cut with esim_shard_population and run as a "
                       "population of its own), steps 1..%d, oracle/esim_refshape.cpp on %d threads: %.1f s (+ %.1f s to build its structures)"
                       % (int(cuts[1]), sample.n_citizens, steps, threads, spent, build),

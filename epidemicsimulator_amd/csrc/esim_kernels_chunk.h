@@ -1702,16 +1702,24 @@ __device__ __forceinline__ void route_pair_small(const Dev &d, Ctrl *ctrl, const
     uint32_t c = 0, w = 0, key = 0;
     bool inf = false;
     WORK_ADD(WK_ROUTE_PAIRS, lane == 0 ? 1 : 0); WORK_ADD(WK_RIDERS, lane < sz ? 1 : 0);
+    bool can = false;                                                          // could take a draw on this bus step at all
     if (lane < sz) {
         c = d.route_riders[off + lane];
         w = d.cit[c];
         inf = status_in_chunk(d, w, t0, j) == ESIM_INFECTED;
-        key = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
+        const uint32_t te = CW_TE(w);
+        can = !(w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_KEEP)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) || j > CW_VAX_REL(w));
     }
+    // Nobody Infected aboard, or nobody who could still be exposed: no draw is made, whatever the buses (the order of the riders
+    // is only needed to tell who shares a bus with whom).  A route that fills one bus at most needs no order either.
+    if (!__any(inf) || !__any(can)) return;
     uint32_t rank = 0;
-    for (uint32_t i = 0; i < sz; ++i) {
-        const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)i);   // i is uniform: a scalar broadcast
-        rank += ki < key || (ki == key && i < lane);                     // ids ascend with the lane
+    if (sz > d.bus_capacity) {
+        if (lane < sz) key = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
+        for (uint32_t i = 0; i < sz; ++i) {
+            const uint32_t ki = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)i);   // i is uniform: a scalar broadcast
+            rank += ki < key || (ki == key && i < lane);                     // ids ascend with the lane
+        }
     }
     const uint32_t bus = rank / d.bus_capacity;
     // Infected riders on my bus: one ballot per bus of the route
@@ -1722,13 +1730,10 @@ __device__ __forceinline__ void route_pair_small(const Dev &d, Ctrl *ctrl, const
         const unsigned long long on_b = __ballot(lane < sz && bus == b);
         if (bus == b) k = (uint32_t)__popcll(on_b & inf_m);
     }
-    if (lane < sz && k) {
-        const uint32_t te = CW_TE(w);
-        if (!(w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_KEEP)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) || j > CW_VAX_REL(w))) {   // not exposed before this bus, not Vaccinated by then
-            const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
-            WORK_ADD(WK_BUS_DRAWS, 1);
-            if (esim_u32(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) { WORK_ADD(WK_HITS, 1); expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED); }
-        }
+    if (lane < sz && k && can) {                                               // not exposed before this bus, not Vaccinated by then
+        const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
+        WORK_ADD(WK_BUS_DRAWS, 1);
+        if (esim_u32(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) { WORK_ADD(WK_HITS, 1); expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED); }
     }
 }
 
@@ -2052,12 +2057,20 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
         const uint32_t off = d.route_off[r], sz = d.route_off[r + 1] - off;
         const uint32_t s = t0 + j, mask = sm.dec[j].mask;
         WORK_ADD(WK_ROUTE_PAIRS, threadIdx.x == 0 ? 1 : 0);
+        int loc_inf = 0, loc_can = 0;
         for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
             const uint32_t c = d.route_riders[off + i];
             WORK_ADD(WK_RIDERS, 1);
-            rs.s_key[i] = philox4x32_10(d.id_base + c, s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
-            rs.s_inf[i] = status_in_chunk(d, d.cit[c], t0, j) == ESIM_INFECTED ? 1 : 0;
+            const uint32_t w = d.cit[c], te = CW_TE(w);
+            rs.s_inf[i] = status_in_chunk(d, w, t0, j) == ESIM_INFECTED ? 1 : 0;
+            loc_inf |= rs.s_inf[i];
+            loc_can |= !(w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_KEEP)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) || j > CW_VAX_REL(w)) ? 1 : 0;
         }
+        // (nobody Infected aboard, or nobody who could still be exposed: no draw is made, whatever the order of the riders)
+        const int any_inf = __syncthreads_or(loc_inf), any_can = __syncthreads_or(loc_can);
+        if (!any_inf || !any_can) continue;
+        for (uint32_t i = threadIdx.x; i < sz; i += TPB)
+            rs.s_key[i] = philox4x32_10(d.id_base + d.route_riders[off + i], s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
         for (uint32_t i = threadIdx.x; i < sz / d.bus_capacity + 1u; i += TPB) rs.s_cnt[i] = 0u;
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < sz; i += TPB) {

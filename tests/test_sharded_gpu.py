@@ -224,4 +224,5 @@ def test_bench_one_gpu_line():
     assert d["steps"] == 20 and d["golden_check"]["records_compared"] == 20
     assert d["full_run"]["steps"] == 5000 and d["full_run"]["golden_check"]["records_compared"] == 200
     assert d["full_run"]["steps_with_vaccination_active"] > 3800 and d["full_run"]["sequential_steps"] < 50
-    assert d["cpu_baseline"]["kind"] == "reference-shaped" and d["cpu_baseline"]["records_match_gpu"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["shape"].startswith("reference-shaped") and d["cpu_baseline"]["records_match_gpu"]
+    assert d["dtype"].startswith("u32 citizen word; u32 uniform")
