@@ -421,13 +421,13 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         // matter of speed only.  Room for the smaller of: every long member list marked in every step; a quarter of the
         // citizens -- twice over, since the queues fill unevenly.
         size_t units = 0;
-        auto add_lists = [&](const std::vector<uint32_t> &off, size_t u_pairs) {
+        auto add_lists = [&](const std::vector<uint32_t> &off) {
             for (size_t i = 0; i + 1 < off.size(); ++i) {
                 const size_t pairs = (size_t)(off[i + 1] - off[i]) * FREE_MAX;
-                if (pairs > u_pairs) units += (pairs + u_pairs - 1) / u_pairs;
+                if (pairs > UNIT_PAIRS) units += (pairs + UNIT_PAIRS - 1) / UNIT_PAIRS;
             }
         };
-        add_lists(res_off, UNIT_PAIRS); add_lists(wrk_off, UNIT_PAIRS); add_lists(room_off, UNIT_PAIRS / 4u);   // (a room's units shrink with its Infected)
+        add_lists(res_off); add_lists(wrk_off); add_lists(room_off);
         units = std::min<size_t>(units, (size_t)N / 8u + 65536u);
         d.unit_qcap = (uint32_t)std::max<size_t>(1024, units * 2u / SUBQ);
         if ((rc = dev_alloc(c, &d.units, (size_t)d.unit_qcap * SUBQ))) return rc;

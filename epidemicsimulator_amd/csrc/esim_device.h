@@ -135,7 +135,7 @@ static inline __host__ __device__ uint32_t err_decode(uint32_t word)
 
 // A deferred unit of a long member list: UNIT_PAIRS (member, marked step) pairs from pair p_lo on.  code = kind << 30 | p_lo
 // (UNIT_NOOP: skip); m_first = the member its first pair belongs to.
-struct UnitRec { uint32_t slot, link, lo, n_mem, code, own, m_first, n_pairs; };   // n_pairs: pairs of this unit (<= UNIT_PAIRS)
+struct UnitRec { uint32_t slot, link, lo, n_mem, code, own, m_first, pad; };
 
 // An item of a time-parallel chunk: a building (a = residents, b = workers, aux = type), a school room (a =
 // participants, aux = its school building) or a route.

@@ -1582,14 +1582,12 @@ __device__ __forceinline__ void school_counts(const Dev &d, uint32_t s_sch, uint
 struct UnitSrc { uint32_t slot, link, own; };
 __device__ __forceinline__ void list_or_units(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, WaveScratch &ws, const uint32_t *idx,
                                               uint32_t lo, uint32_t hi, const UnitSrc &src, uint32_t lane, uint32_t kind, uint32_t S, uint32_t t0 WORK_ARG,
-                                              bool have_pre = false, uint32_t pre_m = 0u, uint32_t pre_w = 0u, uint32_t u_pairs = UNIT_PAIRS)
+                                              bool have_pre = false, uint32_t pre_m = 0u, uint32_t pre_w = 0u)
 {
-    // u_pairs: pairs per unit -- fewer for a school room with several Infected (a pair there is one Philox block per Infected
-    // room-mate: units of equal pairs were units of up to 48 us beside ones of 5)
     const uint32_t pairs = (hi - lo) * S;
     if (pairs == 0) return;
-    if (pairs <= u_pairs) { member_pairs(d, ctrl, sm, ws, idx, lo, 0u, pairs, lane, kind, S, t0 WORK_PASS, have_pre, pre_m, pre_w); return; }
-    const uint32_t n_units = (pairs + u_pairs - 1u) / u_pairs;
+    if (pairs <= UNIT_PAIRS) { member_pairs(d, ctrl, sm, ws, idx, lo, 0u, pairs, lane, kind, S, t0 WORK_PASS, have_pre, pre_m, pre_w); return; }
+    const uint32_t n_units = (pairs + UNIT_PAIRS - 1u) / UNIT_PAIRS;
     const uint32_t r = ((blockIdx.x * TPB + threadIdx.x) >> 6) & (SUBQ - 1u);  // this wavefront's queue
     uint32_t start = 0;
     if (lane == 0) start = atomicAdd(&d.hot[(HOT_UNITS + r) * HOT_STRIDE], n_units);
@@ -1602,8 +1600,8 @@ __device__ __forceinline__ void list_or_units(const Dev &d, Ctrl *ctrl, const Ch
         return;
     }
     for (uint32_t i = lane; i < n_units; i += 64u) {
-        const uint32_t p_lo = i * u_pairs;
-        q[start + i] = UnitRec{ src.slot, kind == 2u ? src.link : 0xFFFFFFFFu, lo, hi - lo, (kind << 30) | p_lo, src.own, p_lo / S, u_pairs };
+        const uint32_t p_lo = i * UNIT_PAIRS;
+        q[start + i] = UnitRec{ src.slot, kind == 2u ? src.link : 0xFFFFFFFFu, lo, hi - lo, (kind << 30) | p_lo, src.own, p_lo / S, 0u };
     }
 }
 
@@ -1913,9 +1911,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
             __builtin_amdgcn_wave_barrier();
             // School::find_exposures: the room once per infected in it (building.rs:494-522)
             const UnitSrc src = { it.slot, it.link, FX(x, 7) };
-            uint32_t km = max(it.c0, it.c1);                                  // the most Infected the room holds in a step of the chunk
-            for (int o = 32; o > 0; o >>= 1) km = max(km, (uint32_t)__shfl_xor((int)km, o, 64));
-            list_or_units(d, ctrl, sm, ws, d.room_idx, it.a_lo, it.a_hi, src, lane, 2u, S, t0 WORK_PASS, true, mm, mw, UNIT_PAIRS / min(max(km, 1u), 4u));
+            list_or_units(d, ctrl, sm, ws, d.room_idx, it.a_lo, it.a_hi, src, lane, 2u, S, t0 WORK_PASS, true, mm, mw);
         }
         __builtin_amdgcn_wave_barrier();
         { const uint32_t dt = PROF_NOW() - pi0; p_item_max = dt > p_item_max ? dt : p_item_max; }
@@ -2032,10 +2028,9 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
         __builtin_amdgcn_wave_barrier();
         const uint32_t pairs = n_mem * S;
         WORK_ADD(WK_UNITS, lane == 0 ? 1 : 0);
-        const uint32_t u_len = min(max(FX(u, 7), 1u), UNIT_PAIRS);             // (pairs of this unit: the producer's choice)
-        member_pairs(d, ctrl, sm, ws, idx, lo, p_lo, min(pairs, p_lo + u_len), lane, kind, S, t0 WORK_PASS, true, mid, mw, mf);
+        member_pairs(d, ctrl, sm, ws, idx, lo, p_lo, min(pairs, p_lo + UNIT_PAIRS), lane, kind, S, t0 WORK_PASS, true, mid, mw, mf);
         __builtin_amdgcn_wave_barrier();
-        { const uint32_t dt = PROF_NOW() - pui; pu_max = dt > pu_max ? dt : pu_max; pu_it += (min(pairs, p_lo + u_len) - p_lo + 63u) / 64u; }
+        { const uint32_t dt = PROF_NOW() - pui; pu_max = dt > pu_max ? dt : pu_max; pu_it += (min(pairs, p_lo + UNIT_PAIRS) - p_lo + 63u) / 64u; }
     }
     const uint32_t pu2 = PROF_NOW();
     WORK_FLUSH(d);
