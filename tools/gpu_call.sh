@@ -9,7 +9,8 @@ for step in $steps; do
     tests) timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_$tag.log 2>&1; rc=$?; tail -5 gpurun_out/pytest_$tag.log; [ $rc -eq 0 ] || exit $rc ;;
     calib) timeout -k 10 300 bash tools/calib_passes.sh > gpurun_out/calib_$tag.log 2>&1; rc=$?; tail -12 gpurun_out/calib_$tag.log; cp profiles/calib_tcc_calibration.* gpurun_out/ 2>/dev/null; [ $rc -eq 0 ] || exit $rc ;;
     prof) timeout -k 10 900 bash tools/profile_passes_r03.sh $tag uk64m > gpurun_out/prof_$tag.log 2>&1; rc=$?; tail -70 gpurun_out/prof_$tag.log; cp profiles/${tag}_* gpurun_out/ 2>/dev/null; [ $rc -eq 0 ] || exit $rc ;;
-    bench)            timeout -k 10 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err; rc=$?; cut -c1-2500 gpurun_out/bench_$tag.json; [ $rc -eq 0 ] || { tail -5 gpurun_out/bench_$tag.err; exit $rc; } ;;
+    bench) [ -f profiles/${tag}_summary.json ] && cp profiles/${tag}_summary.json profiles/current_uk64m.json
+           timeout -k 10 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err; rc=$?; cut -c1-2500 gpurun_out/bench_$tag.json; [ $rc -eq 0 ] || { tail -5 gpurun_out/bench_$tag.err; exit $rc; } ;;
     ab) for i in 1 2; do
           for m in "1 1" "2 2" "4 4" "4 1" "1 4" "8 8"; do set -- $m; echo -n "draw x$1 units x$2: "; ESIM_DRAW_MULT=$1 ESIM_UNITS_MULT=$2 timeout -k 10 200 python tools/run_preset.py uk64m | grep us/step | cut -c1-120 || exit 5; done
         done ;;
