@@ -453,6 +453,18 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
                 if ((rc = dev_alloc(c, &d.sch_ring, (size_t)(n_sch ? n_sch : 1) * 2u * SCH_RING))) return rc;
                 HIP_TRY(c, hipMemset(d.sch_ring, 0, sizeof(uint32_t) * (size_t)(n_sch ? n_sch : 1) * 2u * SCH_RING));
             }
+            {
+                // the records k_chunk_marks reads with one request each (Dev::where4, Dev::bld8), and the schools' difference arrays
+                std::vector<uint4> w4(N ? N : 1);
+                for (uint32_t i = 0; i < N; ++i) w4[i] = make_uint4(pop->home_building[i], pop->work_building[i], room_fixed[i], route_of[i]);
+                if ((rc = dev_upload(c, &d.where4, w4.data(), w4.size()))) return rc;
+                std::vector<BldRec> b8(B ? B : 1);
+                for (uint32_t b = 0; b < B; ++b) b8[b] = BldRec{ res_off[b], res_off[b + 1], wrk_off[b], wrk_off[b + 1], (uint32_t)pop->building_type[b], ovf_off[b], ovf_off[b + 1], 0u };
+                if ((rc = dev_upload(c, &d.bld8, b8.data(), b8.size()))) return rc;
+                const size_t sd = (size_t)(d.n_sch ? d.n_sch : 1) * SD_REPL * 2u * FREE_MAX;
+                if ((rc = dev_alloc(c, &d.sch_diff, sd))) return rc;
+                HIP_TRY(c, hipMemset(d.sch_diff, 0, sizeof(uint32_t) * sd));
+            }
             d.ovf_room_base = ovf_off.back();
             // (the persistent map keeps two places per member -- a record and a cancellation -- and the routes' riders behind the rooms)
             d.ovf_route_base = d.ovf_room_base + room_off.back();

@@ -137,6 +137,10 @@ static inline __host__ __device__ uint32_t err_decode(uint32_t word)
 // (UNIT_NOOP: skip); m_first = the member its first pair belongs to.
 struct UnitRec { uint32_t slot, link, lo, n_mem, code, own, m_first, pad; };
 
+// A building as k_chunk_marks needs it when it claims its item or spills a record: residents, workers, type, overflow stretch.
+struct BldRec { uint32_t res_lo, res_hi, wrk_lo, wrk_hi, type, ovf_lo, ovf_hi, pad; };
+#define SD_REPL 8u
+
 // An item of a time-parallel chunk: a building (a = residents, b = workers, aux = type), a school room (a =
 // participants, aux = its school building) or a route.
 struct ItemRec { uint32_t id, a_lo, a_hi, b_lo, b_hi, aux, link, own; };   // link: a room's school item; own: the claimer's interval record
@@ -212,6 +216,14 @@ struct Dev {
     const int32_t *sch_of_bld;  // [n_bld] dense school index, -1: not a school
     uint32_t *sch_ring;         // [n_sch][2][SCH_RING]
     uint32_t n_sch;
+    // school buildings of the per-chunk map: everybody Infected in one adds its stretch of the chunk to a DIFFERENCE array of the
+    // school (+1 at its first step, -1 behind its last; a second array for those who ride public transport) instead of one
+    // counter atomic per step; SD_REPL copies by adding wavefront, so that the hundreds of Infected of one school do not queue
+    // on one address; k_chunk_fold sums them up into the slot's `vec` and zeroes them
+    uint32_t *sch_diff;         // [n_sch][SD_REPL][2][FREE_MAX]
+    // what k_chunk_marks needs of a citizen / of a building in one 16- / 32-byte record (one memory request instead of four / three)
+    const uint4 *where4;        // [n] home building, work building, room, route (as home / work / room / route_of)
+    const struct BldRec *bld8;  // [n_bld]
     uint32_t ovf_route_base;    // records of a route's Infected riders: ovf[2 * (ovf_route_base + route_off[r]) ...)
     uint32_t *big_list;         // [SUBQ][big_qcap][3] slots with records in `ovf`, where those start and how many fit, listed by the first
                                 // to put one there; 64 lists by listing wavefront & 63, lengths in hot[HOT_BIG ...]
@@ -301,7 +313,7 @@ struct Dev {
 // where a device-side error was raised (Ctrl::err_where)
 #define RAISE(ctrl, code, where) do { (ctrl)->error = (uint32_t)(-(code)); (ctrl)->err_where = (where); } while (0)
 enum { ERR_AT_OVF_FULL = 1, ERR_AT_BIG_LIST, ERR_AT_NEG_LIST, ERR_AT_ITEM_IDS, ERR_AT_HASH_FULL, ERR_AT_ITEM_CHECK, ERR_AT_ROUTE_ITEM, ERR_AT_MAP_STATE,
-       ERR_AT_CANCEL_SLOT, ERR_AT_BIGPAIRS };
+       ERR_AT_CANCEL_SLOT, ERR_AT_BIGPAIRS, ERR_AT_SCHOOL };
 #define SCH_RING 1024u             // >= exposed_time + infected_time + 2 + 2 * FREE_MAX
 #define PBIG_STRIDE 4u             // words per entry of the persistent map's fold list: slot, overflow base, capacity | school flag, school
 #define NEG_CAP (1u << 18)          // cancellation records per chunk (a chunk plans at most 96 x 8192 vaccinations, few of them of Infected citizens)

@@ -1020,10 +1020,10 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         if (any_home || any_work || any_bus) { ++p_entries; WORK_ADD(WK_ENTRIES, 1); }
         // the four keys: home building, work building, room, route
         uint32_t src[4] = { 0u, r_bld, r_room, 0u };
-        if (any_home) src[0] = d.home[c];
-        if (any_work && !remote) src[1] = d.work[c];
-        if (any_work && school && !remote) src[2] = d.room[c];
-        if (any_bus) src[3] = d.route_of[c];
+        if (!remote && (any_home || any_work || any_bus)) {
+            const uint4 k4 = d.where4[c];                                      // (one request for the four)
+            src[0] = k4.x; src[1] = k4.y; src[2] = k4.z; src[3] = k4.w;
+        }
         unsigned long long key[4];
         key[0] = any_home ? (unsigned long long)src[0] : HKEY_EMPTY;
         key[1] = any_work ? (unsigned long long)src[1] : HKEY_EMPTY;
@@ -1087,9 +1087,9 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
                 ItemRec rec = { id, 0u, 0u, 0u, 0u, 0u, k == 2u ? slot[1] : 0xFFFFFFFFu,
                                 k == 0u ? iv_home : (k == 1u && !school) || k == 2u ? iv_work : 0u };
                 if (k == 0u || k == 1u) {
-                    rec.a_lo = d.res_off[id]; rec.a_hi = d.res_off[id + 1u];
-                    rec.b_lo = d.wrk_off[id]; rec.b_hi = d.wrk_off[id + 1u];
-                    rec.aux = (uint32_t)d.bld_type[id];
+                    const uint4 b4 = *reinterpret_cast<const uint4 *>(&d.bld8[id]);
+                    rec.a_lo = b4.x; rec.a_hi = b4.y; rec.b_lo = b4.z; rec.b_hi = b4.w;
+                    rec.aux = d.bld8[id].type;
                 } else if (k == 2u) {
                     const uint32_t r = id - d.n_bld;
                     rec.a_lo = d.room_off[r]; rec.a_hi = d.room_off[r + 1u];
@@ -1124,16 +1124,33 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
         // building); the first to get there lists the slot for k_chunk_fold
         bool direct[3], first[3];
         uint32_t first_base[3] = { 0u, 0u, 0u }, first_cap[3] = { 0u, 0u, 0u };
+        if (school && key[1] != HKEY_EMPTY) {
+            // a school building: my stretch goes into the school's difference arrays (two atomics, four for a rider, whatever
+            // the number of steps); whoever claimed the building's item lists it for k_chunk_fold
+            const int32_t sch = d.sch_of_bld[(uint32_t)key[1]];
+            if (sch < 0 || (uint32_t)sch >= d.n_sch) RAISE(ctrl, ESIM_ERANGE, ERR_AT_SCHOOL);
+            else {
+                uint32_t *dd = d.sch_diff + ((size_t)sch * SD_REPL + (wave & (SD_REPL - 1u))) * 2u * FREE_MAX;
+                WORK_ADD(WK_DIRECT, (w & FL_USES_PT) ? 4 : 2);
+                atomicAdd(&dd[iv_a], 1u);
+                if (iv_b + 1u < FREE_MAX) atomicAdd(&dd[iv_b + 1u], 0xFFFFFFFFu);
+                if (w & FL_USES_PT) {
+                    atomicAdd(&dd[FREE_MAX + iv_a], 1u);
+                    if (iv_b + 1u < FREE_MAX) atomicAdd(&dd[FREE_MAX + iv_b + 1u], 0xFFFFFFFFu);
+                }
+                if (claimed[1]) { first_base[1] = (uint32_t)sch; first_cap[1] = 0xFFFFFFFFu; }
+            }
+        }
 #pragma unroll
         for (uint32_t k = 0; k < 3u; ++k) {
-            direct[k] = k == 1u && school && key[1] != HKEY_EMPTY; first[k] = false;
+            direct[k] = false; first[k] = k == 1u && first_cap[1] == 0xFFFFFFFFu;
             if (!add_rec[k]) continue;
             WORK_ADD(WK_RECORDS, 1);
             const uint32_t iv = k == 0u ? iv_home : iv_work;
             if (old[k] < ITEM_RECS) { d.slot_iv[(size_t)slot[k] * SLOT_IV_STRIDE + old[k]] = iv; continue; }
             const uint32_t q = old[k] - ITEM_RECS, id = (uint32_t)key[k];
             uint32_t base, cap;
-            if (k < 2u) { base = d.ovf_off[id]; cap = d.ovf_off[id + 1u] - base; }
+            if (k < 2u) { base = d.bld8[id].ovf_lo; cap = d.bld8[id].ovf_hi - base; }
             else { const uint32_t r = id - d.n_bld; const uint32_t o = d.room_off[r]; base = d.ovf_room_base + o; cap = d.room_off[r + 1u] - o; }
             if (q < cap) { d.ovf[base + q] = iv; first[k] = q == 0u; first_base[k] = base; first_cap[k] = cap; }
             else direct[k] = true;
@@ -1283,6 +1300,11 @@ __global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
             slot_l = bl[l_stride * mine]; base_l = bl[l_stride * mine + 1u];
             const uint32_t cap_l = bl[l_stride * mine + 2u] & 0x7FFFFFFFu, all_ovf = bl[l_stride * mine + 2u] >> 31;   // (bit 31: a school building of the persistent map)
             if (PM && all_ovf) { sch_l = bl[l_stride * mine + 3u]; if (sch_l >= d.n_sch) { sch_l = 0xFFFFFFFFu; RAISE(ctrl, ESIM_ERANGE, ERR_AT_BIG_LIST); } }
+            if (!PM && all_ovf) {
+                // a school building (k_chunk_marks: capacity word 0xFFFFFFFF, the school's number where the records would start)
+                sch_l = base_l; base_l = 0u;
+                if (sch_l >= d.n_sch || slot_l >= d.hcap) { sch_l = 0xFFFFFFFFu; slot_l = 0u; RAISE(ctrl, ESIM_ERANGE, ERR_AT_BIG_LIST); }
+            } else
             if (slot_l < d.hcap && base_l <= d.ovf_n && cap_l <= d.ovf_n - base_l) {
                 const uint32_t state = d.slot_state[slot_l];
                 if (PM) { const uint32_t cnt = state & PSLOT_COUNT, inl = all_ovf ? 0u : ITEM_RECS; n_ov_l = min(cnt > inl ? cnt - inl : 0u, cap_l); }
@@ -1338,6 +1360,32 @@ __global__ __launch_bounds__(TPB) void k_chunk_fold(Dev d)
                     const int te = base_te - 1 - (int)z;
                     if (te >= 0) { d.sch_ring[(size_t)sch * 2u * SCH_RING + ((uint32_t)te & (SCH_RING - 1u))] = 0u; d.sch_ring[((size_t)sch * 2u + 1u) * SCH_RING + ((uint32_t)te & (SCH_RING - 1u))] = 0u; }
                 }
+            }
+            if (!PM && FX(sch_l, i) != 0xFFFFFFFFu) {
+                // A school building of the per-chunk map: the prefix sums of its difference arrays are its Infected per step -- all of
+                // them, and the riders among them --; they stand there while those with a work place are at work, the riders not
+                // while riders are on a bus (what k_chunk_marks' `atw` says per citizen).  The arrays are zeroed for the next chunk.
+                uint32_t *dd = d.sch_diff + (size_t)FX(sch_l, i) * SD_REPL * 2u * FREE_MAX;
+                uint32_t a0 = 0u, a1 = 0u, p0 = 0u, p1 = 0u;
+#pragma unroll
+                for (uint32_t r = 0; r < SD_REPL; ++r) {
+                    uint32_t *rr = dd + (size_t)r * 2u * FREE_MAX;
+                    a0 += rr[lane]; p0 += rr[FREE_MAX + lane];
+                    if (lane < FREE_MAX - 64u) { a1 += rr[64u + lane]; p1 += rr[FREE_MAX + 64u + lane]; }
+                }
+#pragma unroll
+                for (uint32_t r = 0; r < SD_REPL; ++r) {
+                    uint32_t *rr = dd + (size_t)r * 2u * FREE_MAX;
+                    rr[lane] = 0u; rr[FREE_MAX + lane] = 0u;
+                    if (lane < FREE_MAX - 64u) { rr[64u + lane] = 0u; rr[FREE_MAX + 64u + lane] = 0u; }
+                }
+                for (uint32_t o = 1; o < 64u; o <<= 1) {
+                    const uint32_t ya = __shfl_up(a0, o, 64), yp = __shfl_up(p0, o, 64), yb = __shfl_up(a1, o, 64), yq = __shfl_up(p1, o, 64);
+                    if (lane >= o) { a0 += ya; p0 += yp; a1 += yb; p1 += yq; }
+                }
+                a1 += __shfl(a0, 63, 64); p1 += __shfl(p0, 63, 64);
+                if (lane < n) c0 = ((AW.lo >> lane) & 1ull) ? a0 - (((BUS.lo >> lane) & 1ull) ? p0 : 0u) : 0u;
+                if (lane < FREE_MAX - 64u && 64u + lane < n) c1 = ((AW.hi >> lane) & 1u) ? a1 - (((BUS.hi >> lane) & 1u) ? p1 : 0u) : 0u;
             }
 #ifdef ESIM_PROFILE_FOLD
             pq_rec += n_ov; ++pq_n;

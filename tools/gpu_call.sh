@@ -35,6 +35,8 @@ for step in $steps; do
     bigfuzz) timeout -k 10 400 python tools/fuzz_parity.py 9000 16 --big > gpurun_out/fuzz_big_$tag.log 2>&1; rc=$?; tail -2 gpurun_out/fuzz_big_$tag.log; [ $rc -eq 0 ] || exit $rc
           ESIM_PMAP_REBUILD=1000 timeout -k 10 400 python tools/fuzz_parity.py 9100 16 --big > gpurun_out/fuzz_bigx_$tag.log 2>&1; rc=$?; tail -2 gpurun_out/fuzz_bigx_$tag.log; [ $rc -eq 0 ] || exit $rc
           ESIM_GRID_CHUNK=16 ESIM_PMAP_REBUILD=3 timeout -k 10 300 python tools/fuzz_parity.py 12000 20 --big > gpurun_out/fuzz_g16_$tag.log 2>&1; rc=$?; tail -1 gpurun_out/fuzz_g16_$tag.log; [ $rc -eq 0 ] || exit $rc ;;
+    kt) timeout -k 10 200 python tools/kernel_times.py uk64m || exit 5 ;;
+    ktgrid) for v in "1024 4" "768 4" "512 8"; do set -- $v; echo -n "grid $1 draw mult $2: "; ESIM_GRID_CHUNK=$1 ESIM_DRAW_MULT=$2 ESIM_UNITS_MULT=$2 timeout -k 10 200 python tools/kernel_times.py uk64m | cut -c40-330 || exit 5; done ;;
     ktimes) ESIM_PMAP=0 timeout -k 10 200 python tools/kernel_times.py uk64m || exit 5
             ESIM_PMAP_REBUILD=1 timeout -k 10 200 python tools/kernel_times.py uk64m || exit 5
             ESIM_PMAP_REBUILD=4 timeout -k 10 200 python tools/kernel_times.py uk64m || exit 5 ;;
