@@ -93,7 +93,7 @@ SYMBOLS = [
     "esim_read_records", "esim_stream", "esim_set_stream",
     "esim_set_exchange_buffer", "esim_synchronize",
     "esim_download_state", "esim_download_exposure_log", "esim_checkpoint_size", "esim_checkpoint_save", "esim_checkpoint_restore", "esim_enable_phase_timing", "esim_phase_timings",
-    "esim_enable_kernel_timing", "esim_kernel_timings", "esim_set_small_step_limit", "esim_small_kernel_timing", "esim_debug_counters",
+    "esim_enable_kernel_timing", "esim_kernel_timings", "esim_set_small_step_limit", "esim_set_tiny_chunk_limit", "esim_small_kernel_timing", "esim_debug_counters",
     "esim_last_error", "esim_destroy",
     "esim_threshold_lut", "esim_synth_preset", "esim_synth_create", "esim_synth_create_shard", "esim_synth_free",
     "esim_shard_population",
@@ -162,6 +162,7 @@ def load():
         "esim_kernel_timings": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
         "esim_debug_counters": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
         "esim_set_small_step_limit": (C.c_int, [vp, C.c_uint32]),
+        "esim_set_tiny_chunk_limit": (C.c_int, [vp, C.c_uint32]),
         "esim_small_kernel_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
         "esim_last_error": (C.c_char_p, [vp]),
         "esim_destroy": (None, [vp]),
@@ -181,8 +182,8 @@ def load():
 
 
 ESIM_OK, ESIM_ERANGE = 0, -5          # include/esim.h
-CHUNK_KERNELS = ("marks", "fold", "draw", "units", "count", "books", "scatter", "vax", "vax_adj", "vax_final", "decide", "future", "map_clear")   # ESIM_CK_*
-PHASE_OF_KERNEL = {"marks": "Generate Exposures", "fold": "Generate Exposures", "draw": "Apply Exposures", "units": "Apply Exposures"}   # the rest: "Apply Interventions"
+CHUNK_KERNELS = ("marks", "fold", "draw", "units", "count", "books", "scatter", "vax", "vax_adj", "vax_final", "decide", "future", "map_clear", "tiny")   # ESIM_CK_*
+PHASE_OF_KERNEL = {"marks": "Generate Exposures", "fold": "Generate Exposures", "draw": "Apply Exposures", "units": "Apply Exposures", "tiny": "Apply Exposures"}   # the rest: "Apply Interventions"
 
 
 def check(code, ctx=None):

@@ -56,6 +56,7 @@ struct esim_ctx_impl {
     // has been enqueued since it was (re)built; a rebuild every pmap_rebuild_every chunks sheds the items of the recovered
     bool pmap = false, map_valid = false, pmap_used = false;      // (off by default: measured slower than the per-chunk rebuild)
     uint32_t pmap_since_rebuild = 0, pmap_rebuild_every = 4;
+    uint32_t tiny_pairs = 2048;                 // chunks with at most this many (Infected, step) pairs at the last read-back run as ONE kernel (k_chunk_tiny; 0: off)
     uint32_t small_grid = 64, small_mult = 4;  // chunks with few Infected: workgroups of the marks / fold kernels, multiplier of the draw kernels (0: off)
     uint32_t draw_mult = 4, units_mult = 4;   // k_chunk_draw / k_chunk_units run this many times the marks grid: more, shorter wavefronts than the chip holds at once
     bool pipeline = true;              // run chunks of steps as one kernel per step while no vaccination programme runs
@@ -78,6 +79,8 @@ struct esim_ctx_impl {
     esim_step_result *pin_rec = nullptr; size_t pin_rec_n = 0;
     uint32_t pin_first = 0, pin_valid = 0;        // records [pin_first, pin_first + pin_valid) of the call in flight are in pin_rec
     bool pin_track = false;
+    bool host_trace = false;                      // ESIM_TRACE_HOST: esim_run prints where its host time went (stderr)
+    std::vector<std::pair<const char *, double>> ht;
     bool ctrl_fresh = false;                      // pin_ctrl holds the control block as it stands (nothing was enqueued since)
     uint32_t stop_flag_dev = 0;                   // what ctrl->stop_when_done holds (written only when it changes)
     // per-kernel device time of the chunk pass (esim_enable_chunk_kernel_timing): an event in front of every kernel of a chunk
@@ -588,6 +591,8 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     c->grid_expose = 1024;
     if (const char *e = std::getenv("ESIM_GRID_INFECTED")) c->grid_infected = (uint32_t)std::max(1, std::atoi(e));   // tuning knobs
     if (const char *e = std::getenv("ESIM_GRID_CHUNK")) c->grid_chunk = (uint32_t)std::min((int)(CHUNK_WAVES_MAX * 64u / TPB), std::max(16, std::atoi(e) / 16 * 16));   // whole groups of 64 wavefronts
+    if (std::getenv("ESIM_TRACE_HOST")) c->host_trace = true;
+    if (const char *e = std::getenv("ESIM_TINY_PAIRS")) c->tiny_pairs = (uint32_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("ESIM_SMALL_GRID")) c->small_grid = (uint32_t)std::max(0, std::atoi(e) / 16 * 16);
     if (const char *e = std::getenv("ESIM_SMALL_MULT")) c->small_mult = (uint32_t)std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("ESIM_PMAP")) c->pmap = std::atoi(e) != 0;
@@ -711,6 +716,13 @@ int fail_dev(esim_ctx_impl *c, uint32_t err)
     return fail(c, -(int)err, "device-side error (S underflow / vaccination window exhausted / a chunk table overflowed)");
 }
 
+static inline void ht_mark(esim_ctx_impl *c, const char *what)
+{
+    if (!c->host_trace) return;
+    timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    c->ht.emplace_back(what, ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3);
+}
+
 // The control block through the pinned mirror: an asynchronous copy and one wait.
 int read_ctrl(esim_ctx_impl *c, Ctrl *h)
 {
@@ -727,10 +739,13 @@ void kd_resolve(esim_ctx_impl *c);
 int burst_readback(esim_ctx_impl *c, uint32_t first, uint32_t span, Ctrl *h)
 {
     const Dev &d = c->d;
+    ht_mark(c, "kernels enqueued");
     HIP_TRY(c, hipMemcpyAsync(c->pin_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
     const bool rec = c->pin_track && first == c->pin_first + c->pin_valid && (size_t)first + span <= c->pin_rec_n;
     if (rec) HIP_TRY(c, hipMemcpyAsync(c->pin_rec + first, d.records + first, sizeof(esim_step_result) * span, hipMemcpyDeviceToHost, c->stream));
+    ht_mark(c, "copies enqueued");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    ht_mark(c, "stream drained");
     *h = *c->pin_ctrl;
     if (rec && h->t >= first) c->pin_valid += std::min<uint32_t>(h->t - first, span);
     c->ctrl_fresh = true;
@@ -854,6 +869,7 @@ void kd_resolve(esim_ctx_impl *c)
 // A chunk with few Infected is nothing but the latency of its kernels: those run on 64 workgroups instead of 1024 then (measured
 // on york, whose chunks are all of that kind: 3.56 instead of 4.0 ms for the 5000 steps).  The choice follows what the last
 // read-back showed, so bursts are kept short while it is in force (the epidemic may double within a hundred steps).
+bool tiny_chunk(const esim_ctx_impl *c) { return c->tiny_pairs && c->last_chunk_pairs <= c->tiny_pairs && c->d.world == 1u && c->d.n_shards == 1u && !c->pmap; }
 bool small_chunk(const esim_ctx_impl *c) { return c->small_grid && c->last_chunk_pairs < 4096u && c->grid_chunk > c->small_grid && !std::getenv("ESIM_GRID_CHUNK"); }
 
 void enqueue_chunk_front(esim_ctx_impl *c)
@@ -1058,11 +1074,22 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             const uint32_t bursts = std::min<uint32_t>((remaining + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n, probing ? 1u : (small_chunk(c) ? 4u : 16u));   // (the form of a chunk's book-keeping is chosen from what the last read-back showed)
             const bool tk = c->kernel_timing;
             if (tk) { if (!c->cev[0]) { (void)hipEventCreate(&c->cev[0]); (void)hipEventCreate(&c->cev[1]); } HIP_TRY(c, hipEventRecord(c->cev[0], c->stream)); }
+            if (tiny_chunk(c)) {
+                // few Infected: every chunk of the burst is ONE launch of one workgroup (esim_kernels_tiny.h); a chunk that has
+                // outgrown that form does not advance, which the read-back below sees
+                c->map_valid = false;
+                for (uint32_t g = 0; g < bursts; ++g) {
+                    kd_mark(c, ESIM_CK_TINY);
+                    hipLaunchKernelGGL(k_chunk_tiny, dim3(1), dim3(FIN_TPB), 0, c->stream, d, g == 0u ? 1 : 0, g + 1u < bursts ? 1 : 0, (uint32_t)c->xf_n, limit_t);
+                }
+                kd_mark(c, ESIM_CK_N);
+            } else {
             kd_mark(c, ESIM_CK_FUTURE);
             hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
             kd_mark(c, ESIM_CK_DECIDE);
             hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 0);
             for (uint32_t g = 0; g < bursts; ++g) enqueue_parallel_chunk(c, g + 1u < bursts ? 1 : 0, limit_t);
+            }
             if (tk) HIP_TRY(c, hipEventRecord(c->cev[1], c->stream));
             Ctrl h;
             if ((rc = burst_readback(c, first, std::min<uint32_t>(remaining, bursts * (uint32_t)c->xf_n), &h))) return rc;
@@ -1136,6 +1163,7 @@ extern "C" int esim_step(esim_ctx *ctx, esim_step_result *out)
 extern "C" int esim_run(esim_ctx *ctx, uint32_t n_steps, int stop_when_done, esim_step_result *out_array, uint32_t *n_done)
 {
     esim_ctx_impl *c = CTX(ctx);
+    if (c && c->host_trace) { c->ht.clear(); ht_mark(c, "enter"); }
     int rc = check_budget(c, n_steps);
     if (rc) return rc;
     if (c->d.n_shards > 1) return fail(c, ESIM_ESTATE, "esim_run: a sharded population needs the split-phase calls and an all-reduce");
@@ -1171,6 +1199,12 @@ extern "C" int esim_run(esim_ctx *ctx, uint32_t n_steps, int stop_when_done, esi
         std::memcpy(out_array, c->pin_rec + first, sizeof(esim_step_result) * done);
     }
     if (n_done) *n_done = done;
+    if (c->host_trace) {
+        ht_mark(c, "exit");
+        std::fprintf(stderr, "[esim host trace] esim_run(%u):", n_steps);
+        for (size_t i = 1; i < c->ht.size(); ++i) std::fprintf(stderr, " %s +%.1f us;", c->ht[i].first, c->ht[i].second - c->ht[i - 1].second);
+        std::fprintf(stderr, " total %.1f us\n", c->ht.back().second - c->ht.front().second);
+    }
     return ESIM_OK;
 }
 
@@ -1850,6 +1884,14 @@ extern "C" int esim_set_small_step_limit(esim_ctx *ctx, uint32_t max_infected)
     esim_ctx_impl *c = CTX(ctx);
     if (!c) return ESIM_EINVAL;
     c->small_max = max_infected;
+    return ESIM_OK;
+}
+
+extern "C" int esim_set_tiny_chunk_limit(esim_ctx *ctx, uint32_t max_pairs)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c) return ESIM_EINVAL;
+    c->tiny_pairs = max_pairs;
     return ESIM_OK;
 }
 

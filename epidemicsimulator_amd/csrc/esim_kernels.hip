@@ -24,4 +24,5 @@
 #include "esim_kernels_common.h"
 #include "esim_kernels_step.h"
 #include "esim_kernels_chunk.h"
+#include "esim_kernels_tiny.h"
 #include "esim_kernels_state.h"

@@ -1785,6 +1785,55 @@ __device__ __forceinline__ void route_pair_small(const Dev &d, Ctrl *ctrl, const
     }
 }
 
+// One (route of more than 64 riders, bus step) pair, by a whole workgroup of NT threads: ranks through LDS (simulator.rs:362-401).
+template <uint32_t NT>
+__device__ __forceinline__ void route_pair_big(const Dev &d, Ctrl *ctrl, const ChunkShared &sm, RouteShared &rs, uint32_t code, uint32_t t0, uint32_t n WORK_ARG)
+{
+    const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
+    const uint32_t r = code >> 7, j = code & 127u;
+    if (r >= d.n_routes || j >= n) { if (threadIdx.x == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); return; }   // (block-uniform)
+    const uint32_t off = d.route_off[r], sz = d.route_off[r + 1] - off;
+    if (sz > CHUNK_ROUTE_MAX) { if (threadIdx.x == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); return; }
+    const uint32_t s = t0 + j, mask = sm.dec[j].mask;
+    WORK_ADD(WK_ROUTE_PAIRS, threadIdx.x == 0 ? 1 : 0);
+    int loc_inf = 0, loc_can = 0;
+    for (uint32_t i = threadIdx.x; i < sz; i += NT) {
+        const uint32_t c = d.route_riders[off + i];
+        WORK_ADD(WK_RIDERS, 1);
+        const uint32_t w = d.cit[c], te = CW_TE(w);
+        rs.s_inf[i] = status_in_chunk(d, w, t0, j) == ESIM_INFECTED ? 1 : 0;
+        loc_inf |= rs.s_inf[i];
+        loc_can |= !(w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_KEEP)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) || j > CW_VAX_REL(w)) ? 1 : 0;
+    }
+    // (nobody Infected aboard, or nobody who could still be exposed: no draw is made, whatever the order of the riders)
+    const int any_inf = __syncthreads_or(loc_inf), any_can = __syncthreads_or(loc_can);
+    if (!any_inf || !any_can) return;
+    for (uint32_t i = threadIdx.x; i < sz; i += NT)
+        rs.s_key[i] = philox4x32_10(d.id_base + d.route_riders[off + i], s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
+    for (uint32_t i = threadIdx.x; i < sz / d.bus_capacity + 1u; i += NT) rs.s_cnt[i] = 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < sz; i += NT) {
+        const uint32_t ki = rs.s_key[i];
+        uint32_t rank = 0;
+        for (uint32_t qq = 0; qq < sz; ++qq) { const uint32_t kq = rs.s_key[qq]; rank += kq < ki || (kq == ki && qq < i); }
+        const uint32_t bus = rank / d.bus_capacity;
+        rs.s_bus[i] = (uint16_t)bus;
+        if (rs.s_inf[i]) atomicAdd(&rs.s_cnt[bus], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < sz; i += NT) {
+        const uint32_t k = rs.s_cnt[rs.s_bus[i]];
+        if (!k) continue;
+        const uint32_t c = d.route_riders[off + i];
+        const uint32_t w = d.cit[c], te = CW_TE(w);
+        if (w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_KEEP)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) || j > CW_VAX_REL(w)) continue;   // exposed before this bus, or Vaccinated by then
+        const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
+        WORK_ADD(WK_BUS_DRAWS, 1);
+        if (esim_u32(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) { WORK_ADD(WK_HITS, 1); expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED); }
+    }
+    __syncthreads();
+}
+
 // PM: the items are those of the persistent map -- ids handed out from SUBQ sub-lists (n_mw = SUBQ), counts from absolute records,
 // routes are items among the others (their records are their Infected riders: the bus steps with any are ranked right here, longer
 // routes go to k_chunk_units' list), and there is no list of (route, step) pairs.
@@ -2098,50 +2147,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_units(Dev d)
             if ((c_code >> 7) < d.n_routes && (c_code & 127u) < n && c_sz <= 64u) route_pair_small(d, ctrl, sm, c_off, c_sz, c_code & 127u, t0, lane WORK_PASS);
         }
     }
-    const uint64_t seed = ((uint64_t)d.seed_hi << 32) | d.seed_lo;
-    for (uint32_t q = blockIdx.x; q < n_pairs; q += gridDim.x) {
-        const uint32_t code = d.route_pairs_big[q], r = code >> 7, j = code & 127u;
-        if (r >= d.n_routes || j >= n) { if (threadIdx.x == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); continue; }   // (block-uniform)
-        const uint32_t off = d.route_off[r], sz = d.route_off[r + 1] - off;
-        const uint32_t s = t0 + j, mask = sm.dec[j].mask;
-        WORK_ADD(WK_ROUTE_PAIRS, threadIdx.x == 0 ? 1 : 0);
-        int loc_inf = 0, loc_can = 0;
-        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
-            const uint32_t c = d.route_riders[off + i];
-            WORK_ADD(WK_RIDERS, 1);
-            const uint32_t w = d.cit[c], te = CW_TE(w);
-            rs.s_inf[i] = status_in_chunk(d, w, t0, j) == ESIM_INFECTED ? 1 : 0;
-            loc_inf |= rs.s_inf[i];
-            loc_can |= !(w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_KEEP)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) || j > CW_VAX_REL(w)) ? 1 : 0;
-        }
-        // (nobody Infected aboard, or nobody who could still be exposed: no draw is made, whatever the order of the riders)
-        const int any_inf = __syncthreads_or(loc_inf), any_can = __syncthreads_or(loc_can);
-        if (!any_inf || !any_can) continue;
-        for (uint32_t i = threadIdx.x; i < sz; i += TPB)
-            rs.s_key[i] = philox4x32_10(d.id_base + d.route_riders[off + i], s, ESIM_SLOT_BUS_ORDER, 0u, d.seed_lo, d.seed_hi).w0;
-        for (uint32_t i = threadIdx.x; i < sz / d.bus_capacity + 1u; i += TPB) rs.s_cnt[i] = 0u;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
-            const uint32_t ki = rs.s_key[i];
-            uint32_t rank = 0;
-            for (uint32_t qq = 0; qq < sz; ++qq) { const uint32_t kq = rs.s_key[qq]; rank += kq < ki || (kq == ki && qq < i); }
-            const uint32_t bus = rank / d.bus_capacity;
-            rs.s_bus[i] = (uint16_t)bus;
-            if (rs.s_inf[i]) atomicAdd(&rs.s_cnt[bus], 1u);
-        }
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < sz; i += TPB) {
-            const uint32_t k = rs.s_cnt[rs.s_bus[i]];
-            if (!k) continue;
-            const uint32_t c = d.route_riders[off + i];
-            const uint32_t w = d.cit[c], te = CW_TE(w);
-            if (w <= CW_MAKE(s + TE_BIAS, CW_BUS_EXPOSED | (w & CW_KEEP)) || (te >= TE_RECOVERED && te != TE_SUSCEPTIBLE) || j > CW_VAX_REL(w)) continue;   // exposed before this bus, or Vaccinated by then
-            const uint32_t row = (!(w & FL_MASK_COMPLIANT) && mask == ESIM_MASK_EVERYWHERE) ? 1u : 0u;
-            WORK_ADD(WK_BUS_DRAWS, 1);
-            if (esim_u32(seed, d.id_base + c, s, ESIM_SLOT_BUS) < sm.thr[row * 256u + (k & 255u)]) { WORK_ADD(WK_HITS, 1); expose_min(d, ctrl, c, w, s, CW_BUS_EXPOSED); }
-        }
-        __syncthreads();
-    }
+    for (uint32_t q = blockIdx.x; q < n_pairs; q += gridDim.x) route_pair_big<TPB>(d, ctrl, sm, rs, d.route_pairs_big[q], t0, n WORK_PASS);
     WORK_FLUSH(d);
 }
 
@@ -2413,12 +2419,10 @@ __global__ __launch_bounds__(FIN_TPB) void k_batch_finish(Dev d, uint32_t t0, ui
 //   [next]    the census ahead and the decisions of the NEXT chunk (k_future + k_decide)
 // It takes (t0, n) from the control block, so that the host can enqueue chunk after chunk without waiting; chunk_done tells
 // k_chunk_scatter (the many-workgroup form of [scatter], used while many citizens are Infected) that the books were written.
-__global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int do_next, uint32_t max_ahead, uint32_t limit_t)
+struct BooksShared { uint32_t e_cnt[2 * FREE_MAX]; uint32_t lo_s[FREE_MAX], cur_s[FREE_MAX]; uint32_t win[BF_WIN]; uint32_t wtmp[FIN_TPB / 64]; };
+__device__ __forceinline__ void books_body(const Dev &d, int fused, int do_next, uint32_t max_ahead, uint32_t limit_t, BooksShared &bs)
 {
-    __shared__ uint32_t e_cnt[2 * FREE_MAX];
-    __shared__ uint32_t lo_s[FREE_MAX], cur_s[FREE_MAX];
-    __shared__ uint32_t win[BF_WIN];
-    __shared__ uint32_t wtmp[FIN_TPB / 64];
+    uint32_t *e_cnt = bs.e_cnt, *lo_s = bs.lo_s, *cur_s = bs.cur_s, *win = bs.win, *wtmp = bs.wtmp;
     Ctrl *ctrl = d.ctrl;
     const uint32_t tid = threadIdx.x;
     const uint32_t pb0 = PROF_NOW();
@@ -2545,4 +2549,10 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int d
     }
     BOOKS_PROF(d, 0, pb1 - pb0); BOOKS_PROF(d, 1, pb2 - pb1); BOOKS_PROF(d, 2, pb3 - pb2); BOOKS_PROF(d, 3, PROF_NOW() - pb3);
     (void)pb0; (void)pb1; (void)pb2; (void)pb3;
+}
+
+__global__ __launch_bounds__(FIN_TPB) void k_chunk_books(Dev d, int fused, int do_next, uint32_t max_ahead, uint32_t limit_t)
+{
+    __shared__ BooksShared bs;
+    books_body(d, fused, do_next, max_ahead, limit_t, bs);
 }

@@ -100,8 +100,10 @@ __device__ __forceinline__ void append(uint32_t *list, uint32_t *len, uint32_t v
 #define PROF_NOW() ((uint32_t)wall_clock64())
 #define PROF_PUT(d, i, v) do { if ((threadIdx.x & 63u) == 0) (d).prof_buf[(size_t)(((blockIdx.x * TPB + threadIdx.x) >> 6)) * PROF_ROW + (i)] = (uint32_t)(v); } while (0)
 #define BOOKS_PROF(d, i, v) do { if (threadIdx.x == 0) (d).prof_buf[(size_t)16383 * PROF_ROW + (i)] = (uint32_t)(v); } while (0)
+#define TINY_PROF(d, i) do { if (threadIdx.x == 0) (d).prof_buf[(size_t)16382 * PROF_ROW + (i)] = (uint32_t)wall_clock64(); } while (0)
 #else
 #define BOOKS_PROF(d, i, v) do { (void)sizeof(v); } while (0)
+#define TINY_PROF(d, i) do { } while (0)
 #define PROF_NOW() 0u
 #define PROF_PUT(d, i, v) do { (void)sizeof(v); } while (0)
 #endif

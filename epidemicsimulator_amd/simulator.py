@@ -331,6 +331,11 @@ class Simulator:
         (0 = always use the multi-workgroup kernels)."""
         _lib.check(self.lib.esim_set_small_step_limit(self._ctx, int(max_infected)), self._ctx)
 
+    def set_tiny_chunk_limit(self, max_pairs):
+        """Time-parallel chunks with at most this many (Infected citizen, step) pairs run as one launch of one workgroup
+        (0 = always the wide form; default 2048)."""
+        _lib.check(self.lib.esim_set_tiny_chunk_limit(self._ctx, int(max_pairs)), self._ctx)
+
     def set_pipeline(self, level):
         """0: sequential steps only; 1: chunks as one kernel per step; 2 (default): time-parallel chunks."""
         _lib.check(self.lib.esim_set_pipeline(self._ctx, int(level)), self._ctx)

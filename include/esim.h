@@ -217,9 +217,10 @@ int  esim_chunk_timing(esim_ctx *ctx, double *total_ms, uint64_t *steps, uint64_
  * the read-back that ends a burst; a kernel's figure includes the boundary to the next one): accumulated ms and launches since
  * the last call, indexed by ESIM_CK_*.  The reference's three phase timers (simulator.rs:137-143) map onto them as
  * "Generate Exposures" = marks + fold, "Apply Exposures" = draw + units, "Apply Interventions" = everything else (plan,
- * decisions, counts, books, scatter) -- apportioned: a chunk pass works on up to 96 steps at once. */
+ * decisions, counts, books, scatter) -- apportioned: a chunk pass works on up to 96 steps at once.  ESIM_CK_TINY: a whole chunk
+ * with few Infected in one launch (census ahead, decisions, marks, draws, books), counted under "Apply Exposures". */
 enum { ESIM_CK_MARKS = 0, ESIM_CK_FOLD, ESIM_CK_DRAW, ESIM_CK_UNITS, ESIM_CK_COUNT, ESIM_CK_BOOKS, ESIM_CK_SCATTER, ESIM_CK_VAX, ESIM_CK_VAX_ADJ,
-       ESIM_CK_VAX_FINAL, ESIM_CK_DECIDE, ESIM_CK_FUTURE, ESIM_CK_MAP_CLEAR, ESIM_CK_N };
+       ESIM_CK_VAX_FINAL, ESIM_CK_DECIDE, ESIM_CK_FUTURE, ESIM_CK_MAP_CLEAR, ESIM_CK_TINY, ESIM_CK_N };
 int  esim_enable_chunk_kernel_timing(esim_ctx *ctx, int enable);
 int  esim_chunk_kernel_timings(esim_ctx *ctx, double ms[ESIM_CK_N], uint64_t calls[ESIM_CK_N]);
 /* Steps run as time-parallel chunks under a vaccination programme (pipeline level 3: the chunk's vaccinations are planned
@@ -284,6 +285,10 @@ int  esim_kernel_timings(esim_ctx *ctx, double *step_ms, uint32_t *out_n);
  * steps of those launches while kernel timing is enabled, then resets the accumulators. */
 int  esim_set_small_step_limit(esim_ctx *ctx, uint32_t max_infected);
 int  esim_small_kernel_timing(esim_ctx *ctx, double *total_ms, uint64_t *steps);
+/* The same idea for time-parallel chunks: while the chunk last read back had at most `max_pairs` (Infected citizen, step) pairs, a
+ * chunk is ONE launch of one workgroup (k_chunk_tiny: census ahead, decisions, marks, draws and books of up to 64 Infected; a
+ * chunk that has outgrown it does not advance and is run in the wide form next).  Default 2048; 0 disables it. */
+int  esim_set_tiny_chunk_limit(esim_ctx *ctx, uint32_t max_pairs);
 /* Pipelined steps: mean duration (ms) of the sampled k_pipe launches, how many were sampled, how many steps ran
  * pipelined since the last call. */
 int  esim_pipeline_timing(esim_ctx *ctx, double *mean_step_ms, uint64_t *steps_timed, uint64_t *steps_run);

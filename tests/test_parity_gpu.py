@@ -31,7 +31,7 @@ def assert_same_state(sim, orc):
 # vaccination programme with the chunk's vaccinations planned ahead), time-parallel chunks until a programme starts and
 # sequential steps from there, chunks as one kernel per step, and sequential steps only with the default hand-over between the
 # persistent single-workgroup kernel and the multi-workgroup kernels, multi-workgroup kernels only, persistent kernel only
-SMALL_LIMITS = ("pmap", "vax", "tp", "pipe", None, 0, 1 << 30)      # the seven execution forms
+SMALL_LIMITS = ("pmap", "vax", "wide", "tinymax", "tp", "pipe", None, 0, 1 << 30)      # the nine execution forms
 
 
 def run_both(pop, steps, check_state_every=None, small_limits=SMALL_LIMITS, **params):
@@ -46,6 +46,10 @@ def _run_both(pop, steps, check_state_every, small_limit, **params):
         sim.set_pipeline(4)                       # ... on the persistent item map (entered once per infection, not per chunk)
     elif small_limit == "vax":
         sim.set_pipeline(3)                       # time-parallel chunks, also under a vaccination programme (default)
+    elif small_limit == "wide":
+        sim.set_pipeline(3); sim.set_tiny_chunk_limit(0)         # ... every chunk in the seven-kernel form, however few the Infected
+    elif small_limit == "tinymax":
+        sim.set_pipeline(3); sim.set_tiny_chunk_limit(1 << 30)   # ... every chunk tried as one launch first (it declines beyond 64 Infected)
     elif small_limit == "tp":
         sim.set_pipeline(2)                       # time-parallel chunks until a vaccination programme starts
     elif small_limit == "pipe":

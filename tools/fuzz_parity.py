@@ -32,6 +32,6 @@ for seed in range(first, first + count):
                   start_hour=int(rng.choice([9, 6, 1])), end_hour=int(rng.choice([17, 20, 23])))
     steps = int(rng.choice([600, 1000, 1500] if BIG else [200, 500, 900]))
     T.run_both(pop, steps, check_state_every=int(rng.choice([17, 50, 97, 125, 300, 1000] if BIG else [50, 125, 300])),
-               small_limits=("pmap", "vax", "tp", "pipe", None) if BIG else T.SMALL_LIMITS, **params)
+               small_limits=("pmap", "vax", "wide", "tinymax", "tp", "pipe", None) if BIG else T.SMALL_LIMITS, **params)
     print("seed %d ok (%d citizens, %d steps, %s)" % (seed, pop.n_citizens, steps, {k: params[k] for k in ("exposure_chance", "exposed_time", "infected_time", "bus_capacity")}), flush=True)
 print("all %d ok in %.0f s" % (count, time.time() - t0))
