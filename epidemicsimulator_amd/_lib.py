@@ -96,7 +96,7 @@ SYMBOLS = [
     "esim_enable_kernel_timing", "esim_kernel_timings", "esim_set_small_step_limit", "esim_set_tiny_chunk_limit", "esim_small_kernel_timing", "esim_debug_counters",
     "esim_last_error", "esim_destroy",
     "esim_threshold_lut", "esim_synth_preset", "esim_synth_create", "esim_synth_create_shard", "esim_synth_free",
-    "esim_shard_population",
+    "esim_shard_population", "esim_shard_cuts",
 ]
 
 # esim_allreduce_fn: int (*)(void *user, int which, void *device_ptr, size_t n_u32)
@@ -170,6 +170,7 @@ def load():
         "esim_synth_preset": (C.c_int, [C.c_char_p, C.POINTER(SynthSpec)]),
         "esim_synth_create": (C.c_int, [C.POINTER(SynthSpec), C.POINTER(PopulationStruct)]),
         "esim_synth_create_shard": (C.c_int, [C.POINTER(SynthSpec), C.c_uint32, C.c_uint32, C.POINTER(PopulationStruct)]),
+        "esim_shard_cuts": (C.c_int, [C.POINTER(PopulationStruct), C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]),
         "esim_synth_free": (None, [C.POINTER(PopulationStruct)]),
         "esim_shard_population": (C.c_int, [C.POINTER(PopulationStruct), _u32p, C.c_uint32, C.c_uint32,
                                             C.POINTER(PopulationStruct)]),

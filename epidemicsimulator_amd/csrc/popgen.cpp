@@ -517,21 +517,42 @@ extern "C" int esim_synth_create(const esim_synth_spec *spec, esim_population *o
     return synth_generate(spec, out);
 }
 
-// The cuts esim_synth_create_shard uses: n_shards bands of whole map rows... of areas with about the same number of citizens.
-static std::vector<uint32_t> even_cuts(const esim_population &whole, uint32_t n_shards)
+// Area boundaries of n_shards bands of the map.  by_work == 0: about the same number of citizens each.  by_work != 0: about the
+// same EXPECTED WORK each -- a citizen is drawn for by the shard it lives on, once per Infected occupant and step in every list it
+// is a member of (its household, its work place, its class room: building.rs:202-204,278-280,494-522), so at a uniform prevalence
+// a citizen's share of the draws is the sum of the sizes of those lists, plus one for its own marks; a band's weight is the sum
+// over the citizens living in it.  (Where the epidemic actually sits is not known before the run: these are static weights.)
+extern "C" int esim_shard_cuts(const esim_population *whole, uint32_t n_shards, int by_work, uint32_t *cuts_out)
 {
-    std::vector<uint64_t> cum(whole.n_areas + 1, 0);
-    for (uint32_t c = 0; c < whole.n_citizens; ++c) cum[whole.building_area[whole.home_building[c]] + 1]++;
-    for (uint32_t a = 0; a < whole.n_areas; ++a) cum[a + 1] += cum[a];
-    std::vector<uint32_t> cuts(n_shards + 1, 0);
-    for (uint32_t k = 1; k < n_shards; ++k) {
-        const uint64_t want = (uint64_t)whole.n_citizens * k / n_shards;
-        cuts[k] = (uint32_t)(std::lower_bound(cum.begin(), cum.end(), want) - cum.begin());
-        cuts[k] = std::max(cuts[k], cuts[k - 1]);
-        cuts[k] = std::min(cuts[k], whole.n_areas);
+    if (!whole || !cuts_out || n_shards == 0) return ESIM_EINVAL;
+    const uint32_t N = whole->n_citizens, B = whole->n_buildings, R = whole->n_rooms, A = whole->n_areas;
+    std::vector<uint64_t> cum((size_t)A + 1, 0);
+    if (!by_work) {
+        for (uint32_t c = 0; c < N; ++c) cum[whole->building_area[whole->home_building[c]] + 1]++;
+    } else {
+        std::vector<uint32_t> res(B, 0), wrk(B, 0), part(R, 0);
+        for (uint32_t c = 0; c < N; ++c) {
+            res[whole->home_building[c]]++;
+            if (whole->room[c] != ESIM_NO_ROOM && whole->room[c] < R) part[whole->room[c]]++;
+            else if (whole->work_building[c] != whole->home_building[c]) wrk[whole->work_building[c]]++;
+        }
+        for (uint32_t c = 0; c < N; ++c) {
+            uint64_t w = 1u + res[whole->home_building[c]];
+            if (whole->room[c] != ESIM_NO_ROOM && whole->room[c] < R) w += part[whole->room[c]];
+            else if (whole->work_building[c] != whole->home_building[c]) w += wrk[whole->work_building[c]];
+            cum[whole->building_area[whole->home_building[c]] + 1] += w;
+        }
     }
-    cuts[n_shards] = whole.n_areas;
-    return cuts;
+    for (uint32_t a = 0; a < A; ++a) cum[a + 1] += cum[a];
+    cuts_out[0] = 0;
+    for (uint32_t k = 1; k < n_shards; ++k) {
+        const uint64_t want = (uint64_t)((unsigned __int128)cum[A] * k / n_shards);
+        uint32_t cut = (uint32_t)(std::lower_bound(cum.begin(), cum.end(), want) - cum.begin());
+        cut = std::max(cut, cuts_out[k - 1]);
+        cuts_out[k] = std::min(cut, A);
+    }
+    cuts_out[n_shards] = A;
+    return ESIM_OK;
 }
 
 extern "C" int esim_synth_create_shard(const esim_synth_spec *spec, uint32_t shard, uint32_t n_shards, esim_population *out)
@@ -541,8 +562,9 @@ extern "C" int esim_synth_create_shard(const esim_synth_spec *spec, uint32_t sha
     esim_population whole;
     int rc = synth_generate(spec, &whole);
     if (rc) return rc;
-    std::vector<uint32_t> cuts = even_cuts(whole, n_shards);
-    rc = esim_shard_population(&whole, cuts.data(), n_shards, shard, out);
+    std::vector<uint32_t> cuts(n_shards + 1, 0);
+    rc = esim_shard_cuts(&whole, n_shards, 1, cuts.data());            // bands of about the same expected work
+    if (!rc) rc = esim_shard_population(&whole, cuts.data(), n_shards, shard, out);
     esim_synth_free(&whole);
     return rc;
 }

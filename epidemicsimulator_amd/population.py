@@ -121,6 +121,15 @@ class Population:
         finally:
             lib.esim_synth_free(C.byref(out))
 
+    def work_cuts(self, n_shards):
+        """Area boundaries giving each shard about the same expected work (esim_shard_cuts: a citizen weighs 1 + the sizes of
+        the lists it is a member of -- household, work place, class room; what esim_synth_create_shard cuts by)."""
+        lib = _lib.load()
+        whole = self.as_struct()
+        cuts = np.zeros(n_shards + 1, np.uint32)
+        _lib.check(lib.esim_shard_cuts(C.byref(whole), n_shards, 1, cuts.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return cuts
+
     def even_cuts(self, n_shards):
         """Area boundaries giving each shard about the same number of citizens."""
         area_of_citizen = self.building_area[self.home_building]

@@ -334,7 +334,7 @@ int  esim_synth_preset(const char *name, esim_synth_spec *out);
  * with esim_synth_free. */
 int  esim_synth_create(const esim_synth_spec *spec, esim_population *out);
 /* The shard `shard` of `n_shards` of the same world: the whole world is generated and cut (esim_shard_population) into
- * bands of the map with about the same number of citizens each; citizen_id_base and n_citizens_global are set, Philox
+ * bands of the map with about the same expected work each (esim_shard_cuts, by_work = 1); citizen_id_base and n_citizens_global are set, Philox
  * counters stay global.  Commuters to a school across a cut make that school (and its rooms) shared. */
 int  esim_synth_create_shard(const esim_synth_spec *spec, uint32_t shard, uint32_t n_shards, esim_population *out);
 void esim_synth_free(esim_population *pop);
@@ -344,6 +344,11 @@ void esim_synth_free(esim_population *pop);
  * (cuts[0..n_shards] are the area boundaries of all shards).  Release with esim_synth_free. */
 int  esim_shard_population(const esim_population *whole, const uint32_t *cuts, uint32_t n_shards,
                            uint32_t shard, esim_population *out);
+/* Area boundaries cuts_out[0..n_shards] of n_shards bands of the map: by_work == 0, about the same number of citizens each;
+ * otherwise about the same expected work each -- a citizen is drawn for by the shard it lives on, in every list it is a member of
+ * (household, work place, class room), so its weight is 1 + the sizes of those lists, a band's the sum over its residents.
+ * Static weights: where the epidemic will sit is not known before the run. */
+int  esim_shard_cuts(const esim_population *whole, uint32_t n_shards, int by_work, uint32_t *cuts_out);
 
 #ifdef __cplusplus
 }

@@ -110,11 +110,27 @@ def test_sharding_covers_the_population():
     assert sum(s.n_seeds for s in shards) == pop.n_seeds
 
 
-def test_generated_shards_are_the_even_cut_of_the_whole():
+def test_generated_shards_are_the_work_balanced_cut_of_the_whole():
     spec = dict(n_citizens=30000, n_areas=90, citizens_per_school=2500, n_seeds=25)
     whole = Population.synthetic("york", **spec)
     shards = [Population.synthetic_shard(i, 4, "york", **spec) for i in range(4)]
-    cut = [whole.shard(whole.even_cuts(4), i) for i in range(4)]
+    wc = whole.work_cuts(4)
+    cut = [whole.shard(wc, i) for i in range(4)]
+    # the bands carry about the same expected work (a citizen: 1 + the sizes of its household, work place, class room), and the
+    # library's citizen-count cuts are what Population.even_cuts computes
+    res = np.bincount(whole.home_building, minlength=whole.n_buildings); in_room = whole.room != 0xFFFFFFFF
+    works = ~in_room & (whole.work_building != whole.home_building)
+    wrk = np.bincount(whole.work_building[works], minlength=whole.n_buildings); part = np.bincount(whole.room[in_room], minlength=whole.n_rooms)
+    w = 1 + res[whole.home_building].astype(np.int64)
+    w[in_room] += part[whole.room[in_room]]; w[works] += wrk[whole.work_building[works]]
+    area = whole.building_area[whole.home_building]
+    band = [int(w[(area >= wc[i]) & (area < wc[i + 1])].sum()) for i in range(4)]
+    assert max(band) < 1.25 * min(band), band
+    ec = np.zeros(5, np.uint32)
+    import ctypes as C
+    st = whole.as_struct()
+    _lib.check(_lib.load().esim_shard_cuts(C.byref(st), 4, 0, ec.ctypes.data_as(C.POINTER(C.c_uint32))))
+    assert ec.tolist() == whole.even_cuts(4).tolist()
     assert [s.citizen_id_base for s in shards] == list(np.cumsum([0] + [s.n_citizens for s in shards[:-1]]))
     assert sum(s.n_citizens for s in shards) == whole.n_citizens
     assert all(s.n_citizens_global == whole.n_citizens for s in shards)
