@@ -184,7 +184,8 @@ def load():
 
 ESIM_OK, ESIM_ERANGE = 0, -5          # include/esim.h
 CHUNK_KERNELS = ("marks", "fold", "draw", "units", "count", "books", "scatter", "vax", "vax_adj", "vax_final", "decide", "future", "map_clear", "tiny")   # ESIM_CK_*
-PHASE_OF_KERNEL = {"marks": "Generate Exposures", "fold": "Generate Exposures", "draw": "Apply Exposures", "units": "Apply Exposures", "tiny": "Apply Exposures"}   # the rest: "Apply Interventions"
+PHASE_OF_KERNEL = {"marks": "Generate Exposures", "fold": "Generate Exposures", "draw": "Apply Exposures", "units": "Apply Exposures"}   # the rest: "Apply Interventions"
+TINY_PHASE_SHARES = {"Generate Exposures": 0.10, "Apply Exposures": 0.40, "Apply Interventions": 0.50}   # k_chunk_tiny: all three in one launch
 
 
 def check(code, ctx=None):

@@ -375,6 +375,12 @@ class Simulator:
         """The same grouped under the reference's three timer labels (simulator.rs:137,140,143), in seconds."""
         out = {"Generate Exposures": 0.0, "Apply Exposures": 0.0, "Apply Interventions": 0.0}
         for k, v in self.chunk_kernel_timings().items():
+            if k == "tiny":
+                # one launch holds all three phases: shared out by the kernel's own stage timers (tools/tiny_stages.py on uk64m:
+                # entries and keys 10 %, the items' draws 40 %, census ahead, decisions and books 50 %)
+                for phase, share in _lib.TINY_PHASE_SHARES.items():
+                    out[phase] += share * v["ms"] * 1e-3
+                continue
             out[_lib.PHASE_OF_KERNEL.get(k, "Apply Interventions")] += v["ms"] * 1e-3
         return out
 

@@ -218,7 +218,8 @@ int  esim_chunk_timing(esim_ctx *ctx, double *total_ms, uint64_t *steps, uint64_
  * the last call, indexed by ESIM_CK_*.  The reference's three phase timers (simulator.rs:137-143) map onto them as
  * "Generate Exposures" = marks + fold, "Apply Exposures" = draw + units, "Apply Interventions" = everything else (plan,
  * decisions, counts, books, scatter) -- apportioned: a chunk pass works on up to 96 steps at once.  ESIM_CK_TINY: a whole chunk
- * with few Infected in one launch (census ahead, decisions, marks, draws, books), counted under "Apply Exposures". */
+ * with few Infected in one launch (census ahead, decisions, marks, draws, books): the Python binding shares it out over the
+ * three labels by the kernel's own stage timers (entries and keys 10 %, draws 40 %, census, decisions and books 50 %). */
 enum { ESIM_CK_MARKS = 0, ESIM_CK_FOLD, ESIM_CK_DRAW, ESIM_CK_UNITS, ESIM_CK_COUNT, ESIM_CK_BOOKS, ESIM_CK_SCATTER, ESIM_CK_VAX, ESIM_CK_VAX_ADJ,
        ESIM_CK_VAX_FINAL, ESIM_CK_DECIDE, ESIM_CK_FUTURE, ESIM_CK_MAP_CLEAR, ESIM_CK_TINY, ESIM_CK_N };
 int  esim_enable_chunk_kernel_timing(esim_ctx *ctx, int enable);
