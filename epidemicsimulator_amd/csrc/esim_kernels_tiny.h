@@ -15,7 +15,7 @@
 #define TINY_E 64u                 // Infected (log entries) of a chunk the one-workgroup form takes
 #define TINY_WAVES (FIN_TPB / 64u)
 #define TINY_INLINE 256u           // member lists of more (member, slot) pairs than this are cut into units of that many, which all wavefronts share
-#define TINY_TASKS 256u
+#define TINY_TASKS 512u
 #define TINY_NONE 0xFFFFFFFFu
 // What one wavefront of the workgroup wrote to memory, the others read after this: the writes have reached the L2 (the workgroup's
 // waves share one CU and one L2: no write-back is needed), the readers drop what their L1 holds of it (a citizen word cached before
@@ -192,12 +192,22 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_tiny(Dev d, int do_first, int
                 const uint32_t pr = n_res * S, pw = n_wrk * S;
                 if (pr && pr <= TINY_INLINE) member_pairs(d, ctrl, sm, ws, d.res_idx, b.res_lo, 0u, pr, lane, 0u, S, t0 WORK_PASS, true, rm, rw);
                 else if (!pr) { }
-                else { const uint32_t nu = (pr + TINY_INLINE - 1u) / TINY_INLINE; uint32_t at = 0u; if (lane == 0) at = atomicAdd(&ts.n_tasks, nu); at = FX(at, 0);
-                       for (uint32_t q = lane; q < nu; q += 64u) { if (at + q < TINY_TASKS) { ts.task[at + q][0] = key; ts.task[at + q][1] = 0u; ts.task[at + q][2] = q * TINY_INLINE; } else RAISE(ctrl, ESIM_ERANGE, ERR_AT_ITEM_IDS); } }
+                else {
+                    // units of TINY_INLINE pairs for everybody; what the queue cannot hold this wavefront draws itself
+                    const uint32_t nu = (pr + TINY_INLINE - 1u) / TINY_INLINE; uint32_t at = 0u; if (lane == 0) at = atomicAdd(&ts.n_tasks, nu); at = FX(at, 0);
+                    const uint32_t fit = at >= TINY_TASKS ? 0u : min(nu, TINY_TASKS - at);
+                    for (uint32_t q = lane; q < fit; q += 64u) { ts.task[at + q][0] = key; ts.task[at + q][1] = 0u; ts.task[at + q][2] = q * TINY_INLINE; }
+                    if (fit < nu) tiny_list(d, ctrl, sm, ws, d.res_idx, b.res_lo, fit * TINY_INLINE, pr, lane, 0u, S, t0 WORK_PASS);
+                }
                 if (pw && pw <= TINY_INLINE) member_pairs(d, ctrl, sm, ws, d.wrk_idx, b.wrk_lo, 0u, pw, lane, 1u, S, t0 WORK_PASS, true, wm, ww);
                 else if (!pw) { }
-                else { const uint32_t nu = (pw + TINY_INLINE - 1u) / TINY_INLINE; uint32_t at = 0u; if (lane == 0) at = atomicAdd(&ts.n_tasks, nu); at = FX(at, 0);
-                       for (uint32_t q = lane; q < nu; q += 64u) { if (at + q < TINY_TASKS) { ts.task[at + q][0] = key; ts.task[at + q][1] = 1u; ts.task[at + q][2] = q * TINY_INLINE; } else RAISE(ctrl, ESIM_ERANGE, ERR_AT_ITEM_IDS); } }
+                else {
+                    // units of TINY_INLINE pairs for everybody; what the queue cannot hold this wavefront draws itself
+                    const uint32_t nu = (pw + TINY_INLINE - 1u) / TINY_INLINE; uint32_t at = 0u; if (lane == 0) at = atomicAdd(&ts.n_tasks, nu); at = FX(at, 0);
+                    const uint32_t fit = at >= TINY_TASKS ? 0u : min(nu, TINY_TASKS - at);
+                    for (uint32_t q = lane; q < fit; q += 64u) { ts.task[at + q][0] = key; ts.task[at + q][1] = 1u; ts.task[at + q][2] = q * TINY_INLINE; }
+                    if (fit < nu) tiny_list(d, ctrl, sm, ws, d.wrk_idx, b.wrk_lo, fit * TINY_INLINE, pw, lane, 1u, S, t0 WORK_PASS);
+                }
             } else {
                 const uint32_t r = key - d.n_bld;
                 const uint32_t a_lo = d.room_off[r], a_hi = d.room_off[r + 1u], sch = d.room_bld[r];
@@ -213,8 +223,13 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_tiny(Dev d, int do_first, int
                 const uint32_t pm = (a_hi - a_lo) * S;
                 if (pm && pm <= TINY_INLINE) member_pairs(d, ctrl, sm, ws, d.room_idx, a_lo, 0u, pm, lane, 2u, S, t0 WORK_PASS, true, mm, mw);
                 else if (!pm) { }
-                else { const uint32_t nu = (pm + TINY_INLINE - 1u) / TINY_INLINE; uint32_t at = 0u; if (lane == 0) at = atomicAdd(&ts.n_tasks, nu); at = FX(at, 0);
-                       for (uint32_t q = lane; q < nu; q += 64u) { if (at + q < TINY_TASKS) { ts.task[at + q][0] = key; ts.task[at + q][1] = 2u; ts.task[at + q][2] = q * TINY_INLINE; } else RAISE(ctrl, ESIM_ERANGE, ERR_AT_ITEM_IDS); } }
+                else {
+                    // units of TINY_INLINE pairs for everybody; what the queue cannot hold this wavefront draws itself
+                    const uint32_t nu = (pm + TINY_INLINE - 1u) / TINY_INLINE; uint32_t at = 0u; if (lane == 0) at = atomicAdd(&ts.n_tasks, nu); at = FX(at, 0);
+                    const uint32_t fit = at >= TINY_TASKS ? 0u : min(nu, TINY_TASKS - at);
+                    for (uint32_t q = lane; q < fit; q += 64u) { ts.task[at + q][0] = key; ts.task[at + q][1] = 2u; ts.task[at + q][2] = q * TINY_INLINE; }
+                    if (fit < nu) tiny_list(d, ctrl, sm, ws, d.room_idx, a_lo, fit * TINY_INLINE, pm, lane, 2u, S, t0 WORK_PASS);
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
