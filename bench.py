@@ -245,6 +245,7 @@ def main():
     pop = Population.synthetic(args.preset)
     params = _lib.default_params(max_steps=5000)
     sim = Simulator(pop, params)
+    sim.enable_kernel_timing(16)                      # (the warm-up takes the same path as the timed call: events and all)
     sim.run(warmup)                                   # W untimed warm-up steps, then back to time step 0
     rec, info = timed_run(sim, steps)
     elapsed = info["wall_us_per_step"] * steps * 1e-6

@@ -2175,6 +2175,11 @@ extern "C" int esim_enable_kernel_timing(esim_ctx *ctx, int enable)
     c->kernel_timing = enable > 0;
     if (enable > 0) c->kernel_timing_stride = (uint32_t)enable;   // time every `enable`-th step
     c->kev_used = 0;
+    if (enable > 0) {                                     // (the events the timed runs record: made here, not inside a timed call)
+        HIP_TRY(c, hipSetDevice(c->P.device));
+        if (!c->cev[0]) { (void)hipEventCreate(&c->cev[0]); (void)hipEventCreate(&c->cev[1]); }
+        if (!c->sev[0]) { (void)hipEventCreate(&c->sev[0]); (void)hipEventCreate(&c->sev[1]); }
+    }
     return ESIM_OK;
 }
 
