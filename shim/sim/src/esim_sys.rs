@@ -105,6 +105,7 @@ extern "C" {
     pub fn esim_phase_timings(ctx: *mut c_void, out: *mut f64) -> c_int;
     // multi-GPU: one context per GPU and process; the exchange between the shards is the library's
     pub fn esim_shard_population(whole: *const EsimPopulation, cuts: *const u32, n_shards: u32, shard: u32, out: *mut EsimPopulation) -> c_int;
+    pub fn esim_shard_cuts(whole: *const EsimPopulation, n_shards: u32, by_work: c_int, cuts_out: *mut u32) -> c_int;
     pub fn esim_synth_free(pop: *mut EsimPopulation);
     pub fn esim_comm_unique_id(out: *mut c_void, cap: usize) -> c_int;
     pub fn esim_comm_init_rccl(ctx: *mut c_void, unique_id: *const c_void, id_bytes: usize, rank: c_int, world: c_int) -> c_int;
