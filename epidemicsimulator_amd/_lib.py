@@ -88,7 +88,7 @@ class SynthSpec(C.Structure):
 SYMBOLS = [
     "esim_default_params", "esim_create", "esim_upload_population", "esim_reset", "esim_step",
     "esim_run", "esim_step_begin", "esim_step_exposures", "esim_step_finish",
-    "esim_exchange_buffer", "esim_future_infected", "esim_run_free", "esim_free_begin", "esim_free_enqueue", "esim_free_collect", "esim_set_pipeline", "esim_chunk_timing", "esim_enable_chunk_kernel_timing", "esim_chunk_kernel_timings", "esim_vax_chunk_stats", "esim_pipeline_timing",
+    "esim_exchange_buffer", "esim_future_infected", "esim_run_free", "esim_free_begin", "esim_free_enqueue", "esim_free_collect", "esim_set_pipeline", "esim_chunk_timing", "esim_enable_chunk_kernel_timing", "esim_chunk_kernel_timings", "esim_vax_chunk_stats", "esim_vax_repair_stats", "esim_pipeline_timing",
     "esim_comm_unique_id", "esim_comm_init_rccl", "esim_comm_init_callback", "esim_comm_set_timeout", "esim_debug_inject_error", "esim_comm_stats", "esim_run_sharded", "esim_shard_stats",
     "esim_read_records", "esim_stream", "esim_set_stream",
     "esim_set_exchange_buffer", "esim_synchronize",
@@ -145,6 +145,7 @@ def load():
         "esim_enable_chunk_kernel_timing": (C.c_int, [vp, C.c_int]),
         "esim_chunk_kernel_timings": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
         "esim_vax_chunk_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "esim_vax_repair_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "esim_pipeline_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "esim_read_records": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.POINTER(StepResult)]),
         "esim_stream": (C.c_int, [vp, pvp]),
@@ -183,7 +184,7 @@ def load():
 
 
 ESIM_OK, ESIM_ERANGE = 0, -5          # include/esim.h
-CHUNK_KERNELS = ("marks", "fold", "draw", "units", "count", "books", "scatter", "vax", "vax_adj", "vax_final", "decide", "future", "map_clear", "tiny")   # ESIM_CK_*
+CHUNK_KERNELS = ("marks", "fold", "draw", "units", "count", "books", "scatter", "vax", "vax_adj", "vax_final", "decide", "future", "map_clear", "tiny", "vax_repair")   # ESIM_CK_*
 PHASE_OF_KERNEL = {"marks": "Generate Exposures", "fold": "Generate Exposures", "draw": "Apply Exposures", "units": "Apply Exposures"}   # the rest: "Apply Interventions"
 TINY_PHASE_SHARES = {"Generate Exposures": 0.10, "Apply Exposures": 0.40, "Apply Interventions": 0.50}   # k_chunk_tiny: all three in one launch
 

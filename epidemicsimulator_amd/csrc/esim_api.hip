@@ -56,6 +56,8 @@ struct esim_ctx_impl {
     // has been enqueued since it was (re)built; a rebuild every pmap_rebuild_every chunks sheds the items of the recovered
     bool pmap = false, map_valid = false, pmap_used = false;      // (off by default: measured slower than the per-chunk rebuild)
     uint32_t pmap_since_rebuild = 0, pmap_rebuild_every = 4;
+    uint64_t vax_chunk_repairs = 0;
+    bool vax_repair = true;                     // planned chunks: repair the plan after bus exposures instead of cutting the chunk (ESIM_VAX_REPAIR=0: cut)
     uint32_t tiny_pairs = 2048;                 // chunks with at most this many (Infected, step) pairs at the last read-back run as ONE kernel (k_chunk_tiny; 0: off)
     uint32_t small_grid = 64, small_mult = 4;  // chunks with few Infected: workgroups of the marks / fold kernels, multiplier of the draw kernels (0: off)
     uint32_t draw_mult = 4, units_mult = 4;   // k_chunk_draw / k_chunk_units run this many times the marks grid: more, shorter wavefronts than the chip holds at once
@@ -513,6 +515,8 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     if ((rc = dev_alloc(c, &d.vax_cnt, FREE_MAX))) return rc;
     if ((rc = dev_alloc(c, &d.vax_now, FREE_MAX))) return rc;
     if ((rc = dev_alloc(c, &d.vax_delta, 4u * (FREE_MAX + 2u)))) return rc;
+    if ((rc = dev_alloc(c, &d.lost_list, LOST_CAP))) return rc;
+    HIP_TRY(c, hipMemset(d.lost_list, 0, sizeof(uint32_t) * LOST_CAP));
     if ((rc = dev_alloc(c, &d.xf_adj, FREE_MAX + 2u))) return rc;
     HIP_TRY(c, hipMemset(d.vax_cnt, 0, sizeof(uint32_t) * FREE_MAX));
     HIP_TRY(c, hipMemset(d.vax_now, 0, sizeof(uint32_t) * FREE_MAX));
@@ -592,6 +596,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     if (const char *e = std::getenv("ESIM_GRID_INFECTED")) c->grid_infected = (uint32_t)std::max(1, std::atoi(e));   // tuning knobs
     if (const char *e = std::getenv("ESIM_GRID_CHUNK")) c->grid_chunk = (uint32_t)std::min((int)(CHUNK_WAVES_MAX * 64u / TPB), std::max(16, std::atoi(e) / 16 * 16));   // whole groups of 64 wavefronts
     if (std::getenv("ESIM_TRACE_HOST")) c->host_trace = true;
+    if (const char *e = std::getenv("ESIM_VAX_REPAIR")) c->vax_repair = std::atoi(e) != 0;
     if (const char *e = std::getenv("ESIM_TINY_PAIRS")) c->tiny_pairs = (uint32_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("ESIM_SMALL_GRID")) c->small_grid = (uint32_t)std::max(0, std::atoi(e) / 16 * 16);
     if (const char *e = std::getenv("ESIM_SMALL_MULT")) c->small_mult = (uint32_t)std::min(16, std::max(1, std::atoi(e)));
@@ -926,7 +931,7 @@ void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
 {
     Dev &d = c->d;
     kd_mark(c, ESIM_CK_VAX);
-    hipLaunchKernelGGL(k_chunk_vax, dim3(FREE_MAX + 1u), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 0);   // (+ the census ahead)
+    hipLaunchKernelGGL(k_chunk_vax<false>, dim3(FREE_MAX + 1u), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 0);   // (+ the census ahead)
     // (persistent map: a rebuild has to be decided BEFORE the plan's cancellation records go into the map)
     const bool pm = c->pmap && d.world == 1u;
     if (pm && (!c->map_valid || c->pmap_since_rebuild >= c->pmap_rebuild_every)) {
@@ -941,6 +946,12 @@ void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
     kd_mark(c, ESIM_CK_DECIDE);
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 0);
     enqueue_chunk_front(c);
+    if (!pm && d.world == 1u && c->vax_repair) {
+        // bus exposures of citizens the plan vaccinates later: the plan of the steps behind is repaired instead of the chunk being cut
+        kd_mark(c, ESIM_CK_VAX_REPAIR);
+        hipLaunchKernelGGL(k_chunk_lost, dim3(1), dim3(FIN_TPB), 0, c->stream, d);
+        hipLaunchKernelGGL(k_chunk_vax<true>, dim3(FREE_MAX), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 0);
+    }
     kd_mark(c, ESIM_CK_COUNT);
     hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
     kd_mark(c, ESIM_CK_BOOKS);
@@ -1049,7 +1060,7 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             const uint32_t done = h.t - first;
             c->last_chunk_pairs = h.chunk_pairs;
             if (tk && done) { float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->cev[0], c->cev[1])); c->chunk_ms += ms; c->chunk_steps += done; c->chunk_count += (done + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n; }
-            c->vax_chunk_steps += done; c->vax_chunk_cuts = h.vax_cuts;
+            c->vax_chunk_steps += done; c->vax_chunk_cuts = h.vax_cuts; c->vax_chunk_repairs = h.vax_repairs;
             c->host_t = h.t; total += done; remaining -= done;
             if (h.finished && allow_early_stop) break;
             if (remaining == 0) break;
@@ -1539,7 +1550,7 @@ int enqueue_sharded_chunk(esim_ctx_impl *c, uint32_t limit_t, bool vax)
     if (vax) {
         hipLaunchKernelGGL(k_vax_live, dim3(PLAN_W / TPB, FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
         if ((rc = exchange_buf(c, 3, d.xv, XV_HEADER + (size_t)FREE_MAX * (PLAN_W / 32u)))) return rc;
-        hipLaunchKernelGGL(k_chunk_vax, dim3(FREE_MAX), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1);
+        hipLaunchKernelGGL(k_chunk_vax<false>, dim3(FREE_MAX), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1);
         hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 0);
     }
     const size_t seg = 1u + 3u * (size_t)d.xs_cap;
@@ -1782,6 +1793,14 @@ extern "C" int esim_vax_chunk_stats(esim_ctx *ctx, uint64_t *steps, uint64_t *cu
     if (!c) return ESIM_EINVAL;
     if (steps) *steps = c->vax_chunk_steps;
     if (cuts) *cuts = c->vax_chunk_cuts;
+    return ESIM_OK;
+}
+
+extern "C" int esim_vax_repair_stats(esim_ctx *ctx, uint64_t *repairs)
+{
+    esim_ctx_impl *c = CTX(ctx);
+    if (!c) return ESIM_EINVAL;
+    if (repairs) *repairs = c->vax_chunk_repairs;
     return ESIM_OK;
 }
 

@@ -120,6 +120,9 @@ struct Ctrl {
     uint32_t err_where;         // diagnostics: which check raised `error` (ERR_AT_*), reported in esim_last_error
     uint32_t peer_error;        // sharded runs: the error fields of ALL shards, summed (ERR_FIELD): every rank takes its return code
                                 // from this word, so that all leave esim_run_sharded together (k_status_unpack)
+    uint32_t replan_from;       // first step of the chunk whose plan is walked again (k_chunk_lost; FREE_MAX + 1: none)
+    uint32_t repair_ran;        // the plan of the chunk in flight was repaired: a cut it ends in is not one of round 2's kind (no CW_PLAN_SKIP marks)
+    uint32_t vax_repairs;       // diagnostics: planned chunks whose plan was repaired after bus exposures instead of being cut (k_chunk_vax<true>)
 };
 
 // A rank's sticky error (1..6 = -ESIM_E*) as a 5-bit field of a word the shards SUM: field c-1 counts the shards that raised
@@ -239,6 +242,7 @@ struct Dev {
     uint32_t *vax_ev;           // [FREE_MAX][VACC_MAX_RATE] citizens chosen in each step of the chunk, in candidate order
     uint32_t *vax_cnt;          // [FREE_MAX] how many (this shard's)
     uint32_t *vax_now;          // [FREE_MAX] vaccinated_now of the step's record (all shards)
+    uint32_t *lost_list;        // [LOST_CAP] citizens whose bus exposure in this chunk found a planned vaccination in their word (expose_min)
     uint32_t *vax_delta;        // [4][FREE_MAX + 2] difference arrays over the chunk's steps: Susceptible, Exposed, Infected, Vaccinated
                                 // census changes caused by the chunk's vaccinations (two's complement)
     uint32_t *xf_adj;           // [FREE_MAX + 2] difference array: Infected census ahead minus those vaccinated before
@@ -309,7 +313,8 @@ struct Dev {
 #define HOT_RPAIRS 193u            // [SUBQ] persistent map: (route of <= 64 riders, bus step) pairs k_chunk_draw registered for k_chunk_units, by wavefront & 63
 #define HOT_PREV_NEWEXP 257u       // [SUBQ] copy of HOT_NEWEXP of the chunk whose log entries k_chunk_scatter is writing
 #define HOT_RESET 257u             // counters k_decide zeroes for a new chunk
-#define HOT_COUNT 321u
+#define HOT_LOST 321u               // citizens exposed on a bus while the chunk's plan had a vaccination for them (Dev::lost_list; zeroed by k_chunk_vax)
+#define HOT_COUNT 322u
 // where a device-side error was raised (Ctrl::err_where)
 #define RAISE(ctrl, code, where) do { (ctrl)->error = (uint32_t)(-(code)); (ctrl)->err_where = (where); } while (0)
 enum { ERR_AT_OVF_FULL = 1, ERR_AT_BIG_LIST, ERR_AT_NEG_LIST, ERR_AT_ITEM_IDS, ERR_AT_HASH_FULL, ERR_AT_ITEM_CHECK, ERR_AT_ROUTE_ITEM, ERR_AT_MAP_STATE,
@@ -318,6 +323,7 @@ enum { ERR_AT_OVF_FULL = 1, ERR_AT_BIG_LIST, ERR_AT_NEG_LIST, ERR_AT_ITEM_IDS, E
 #define PBIG_STRIDE 4u             // words per entry of the persistent map's fold list: slot, overflow base, capacity | school flag, school
 #define NEG_CAP (1u << 18)          // cancellation records per chunk (a chunk plans at most 96 x 8192 vaccinations, few of them of Infected citizens)
 #define UNIT_NOOP 0xFFFFFFFFu
+#define LOST_CAP 8192u              // entries of Dev::lost_list (more: the chunk is cut as before round 3's repair)
 #define CHUNK_BUS_STEPS 8u         // a one-pass chunk has at most this many steps with riders on a bus
 #define COUNT_GRID 256u            // workgroups of k_chunk_count
 #define EXP_ROWS 32u

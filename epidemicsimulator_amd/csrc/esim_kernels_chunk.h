@@ -281,11 +281,52 @@ __global__ __launch_bounds__(TPB) void k_vax_live(Dev d, uint32_t max_ahead, uin
 // and accepts the same candidates, and keeps the events of its own citizens.
 // Launched with one workgroup more than there are steps, that one makes the census ahead (k_future's work: nothing the plan reads
 // or writes, and a kernel boundary costs as much as the census).
+// The citizens expose_min listed (exposed on a bus with a planned vaccination in their word) whose FINAL exposure is that one: they
+// left the eligible set in that step, their planned vaccination is void (the field is cleared here, before any step is walked
+// again: a walk may choose the same citizen anew for an EARLIER step), and the steps from the earliest such exposure on are the
+// ones k_chunk_vax<true> walks again.
+__global__ __launch_bounds__(FIN_TPB) void k_chunk_lost(Dev d)
+{
+    __shared__ uint32_t s_from;
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_chunk = ctrl->chunk_ok, t0 = ctrl->t;
+    const uint32_t n_lost = d.hot[HOT_LOST * HOT_STRIDE];
+    if (!ctrl->vax_chunk || !ctrl->chunk_parallel || n_chunk == 0u || n_lost == 0u || n_lost > LOST_CAP) return;   // (more than the list holds: cut as before)
+    if (tid == 0) s_from = FREE_MAX + 1u;
+    __syncthreads();
+    uint32_t lo = FREE_MAX + 1u;
+    for (uint32_t i = tid; i < n_lost; i += FIN_TPB) {
+        const uint32_t m = d.lost_list[i];
+        if (m >= d.n) continue;
+        const uint32_t w = d.cit[m], e = CW_TE(w) - TE_BIAS - t0;
+        if (!(w & CW_BUS_EXPOSED) || CW_TE(w) >= TE_RECOVERED || e >= n_chunk || CW_VAX_REL(w) == CW_VAX_NONE) continue;   // (listed twice: cleared already)
+        lo = min(lo, e);
+        atomicAnd(&d.cit[m], ~CW_VAX_MASK);
+    }
+    if (lo <= FREE_MAX) atomicMin(&s_from, lo);
+    __syncthreads();
+    if (tid == 0 && s_from <= FREE_MAX) { ctrl->replan_from = s_from; ctrl->repair_ran = 1u; ctrl->vax_repairs += 1u; }
+}
+
+// REPAIR (k_chunk_vax<true>, after the draws of the chunk, before its counts; unsharded contexts on the per-chunk map): a citizen the
+// plan vaccinates at the end of step f was exposed on a bus in step e <= f.  It left the eligible set with that exposure, so in
+// every step from e on in which it was among the chosen the walk takes the next eligible candidate instead -- and nothing else
+// changes: the chosen stay in the set (Q10), so every step's walk is a function of the words alone.  Round 2 cut the chunk at e
+// and threw the draws of everything behind it away (uk64m's last 200 steps, with 17 000 bus exposures per 96 steps, cost 14 of
+// the run's 33 ms that way).  Now the steps from the earliest such e on are walked AGAIN, with eligibility as it truly stood in
+// each step (eligible by the final word, or exposed on a bus in a LATER step of this chunk): the lists of the chosen are rewritten,
+// the lost citizens' fields are cleared, the newly chosen get theirs.  A newly chosen citizen (or one whose vaccination moves to
+// an earlier step) is harmless when nothing it did behind that step mattered: it is not Infected in any later step of the chunk
+// (its marks would have to go, and with them the counts others were drawn with) and was not exposed in a later one.  Otherwise the
+// chunk is cut BEHIND that step (chunk_cut = j + 1): everything up to and including it stands.
+template <bool REPAIR>
 __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead, uint32_t limit_t, int sharded)
 {
     __shared__ FinishShared sm;
     __shared__ uint32_t n_local;
     if (blockIdx.x >= FREE_MAX) {
+        if (REPAIR) return;
         __shared__ uint32_t win[BF_WIN];
         __shared__ uint32_t wtmp[FIN_TPB / 64];
         future_body(d, max_ahead, limit_t, win, wtmp);
@@ -295,17 +336,25 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t j = blockIdx.x;
     const uint32_t t0 = ctrl->t;
-    const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
+    uint32_t n_chunk = 0u;
+    if (REPAIR) {
+        n_chunk = ctrl->chunk_ok;
+        const uint32_t from = ctrl->replan_from;                              // (k_chunk_lost)
+        if (!ctrl->vax_chunk || !ctrl->chunk_parallel || j >= n_chunk || j < from) return;
+    }
+    const uint32_t n_ahead = REPAIR ? n_chunk : (t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead));
     // (every workgroup -- and, sharded, every shard -- takes the same decision from the same words; nothing here writes them)
     const uint32_t elig_all = sharded ? d.xv[0] : ctrl->elig_count, riders_all = sharded ? d.xv[1] : d.n_pt;
     const bool plan = ctrl->have_elig && !ctrl->finished && !ctrl->error && !ctrl->need_seq && !(sharded && d.xv[2]) &&
                       elig_all > d.vaccination_rate + riders_all;      // the set cannot shrink to the "whole set" case inside the chunk
-    if (tid == 0) {
+    if (REPAIR) { if (tid == 0) { d.vax_cnt[j] = 0u; d.vax_now[j] = 0u; n_local = 0u; } }
+    else if (tid == 0) {
         d.xf_adj[j] = 0u;
         for (uint32_t q = 0; q < 4u; ++q) d.vax_delta[q * (FREE_MAX + 2u) + j] = 0u;
         d.vax_cnt[j] = 0u; d.vax_now[j] = 0u;
         n_local = 0u;
         if (j == 0) {
+            d.hot[HOT_LOST * HOT_STRIDE] = 0u; ctrl->replan_from = FREE_MAX + 1u; ctrl->repair_ran = 0u;
             ctrl->vax_chunk = plan ? 1u : 0u;
             ctrl->vax_planned = plan ? n_ahead : 0u;
             ctrl->n_neg = 0u; ctrl->n_cancel = 0u;
@@ -329,6 +378,12 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead
             mine_c[q] = cj[q] >= d.id_base && cj[q] - d.id_base < d.n;
             cw[q] = mine_c[q] ? d.cit[cj[q] - d.id_base] : 0u;
             if (sharded) live[q] = i < PLAN_W && ((bits[i >> 5] >> (i & 31u)) & 1u) != 0u;
+            else if (REPAIR) {
+                // as the set truly stood in this step: who is exposed on a bus in a LATER step of the chunk was still in it
+                const uint32_t e = CW_TE(cw[q]) - TE_BIAS - t0;
+                const bool later_bus = (cw[q] & CW_BUS_EXPOSED) && CW_TE(cw[q]) < TE_RECOVERED && e < n_chunk && e > j;
+                live[q] = (eligible(cw[q], tstep) || later_bus) && !(cw[q] & CW_PLAN_SKIP);
+            }
             else live[q] = eligible(cw[q], tstep) && !(cw[q] & CW_PLAN_SKIP);
             slot[q] = 0;
             if (live[q]) {
@@ -361,7 +416,22 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead
                     const uint32_t c = cj[q] - d.id_base;
                     d.vax_ev[(size_t)j * VACC_MAX_RATE + atomicAdd(&n_local, 1u)] = c;      // (the order inside a step does not matter)
                     // unconditional (simulator.rs:551) -- but a citizen that is Vaccinated already stays what it is
-                    if (CW_TE(cw[q]) != TE_VACCINATED) atomicMax(&d.cit[c], (cw[q] & ~CW_VAX_MASK) | CW_VAX_FIELD(j));
+                    if (CW_TE(cw[q]) != TE_VACCINATED) {
+                        const uint32_t old = atomicMax(&d.cit[c], (cw[q] & ~CW_VAX_MASK) | CW_VAX_FIELD(j));
+                        if (REPAIR && (CW_VAX_REL(old) == CW_VAX_NONE || CW_VAX_REL(old) > j)) {
+                            // newly chosen for this step (or moved here from a later one): harmless unless something it did behind
+                            // step j mattered -- Infected in a later step of the chunk, or exposed in one
+                            const uint32_t te = CW_TE(cw[q]);
+                            bool bad = false;
+                            if (te < TE_RECOVERED) {
+                                const int e = (int)te - (int)TE_BIAS - (int)t0;                                  // exposure step (may lie before the chunk)
+                                const int a = e + (int)d.exposed_time + 1, b = a + (int)d.infected_time;       // Infected in steps a .. b
+                                if (e > (int)j && e < (int)n_chunk) bad = true;
+                                if (max(a, (int)j + 1) <= min(b, (int)n_chunk - 1)) bad = true;
+                            }
+                            if (bad) atomicMin(&ctrl->chunk_cut, j + 1u);
+                        }
+                    }
                 }
                 pos++;
             }
@@ -1444,6 +1514,12 @@ __device__ __forceinline__ void expose_min(const Dev &d, Ctrl *ctrl, uint32_t m,
 {
     const uint32_t cand = CW_MAKE(s + TE_BIAS, bus | (w & CW_KEEP));
     const uint32_t prev = atomicMin(&d.cit[m], cand);
+    // exposed on a bus although the chunk's plan vaccinates it later: it leaves the eligible set with this exposure (simulator.rs:447-449),
+    // so the plan of the steps from here on is off by this citizen -- noted for the repair (k_chunk_vax<true>)
+    if (bus && cand < prev && CW_VAX_REL(w) != CW_VAX_NONE) {
+        const uint32_t at = atomicAdd(&d.hot[HOT_LOST * HOT_STRIDE], 1u);
+        if (at < LOST_CAP) d.lost_list[at] = m;
+    }
     if (cand < prev && CW_TE(prev) == TE_SUSCEPTIBLE) {                       // first exposure in this chunk
         const uint32_t r = m & (SUBQ - 1u);
         d.newexp[(size_t)r * d.newexp_cap + atomicAdd(&d.hot[(HOT_NEWEXP + r) * HOT_STRIDE], 1u)] = m;
@@ -2195,7 +2271,9 @@ __global__ __launch_bounds__(TPB) void k_chunk_count(Dev d)
             const uint32_t w = d.cit[d.vax_ev[(size_t)j * VACC_MAX_RATE + i]], te = CW_TE(w);
             if (CW_VAX_REL(w) != j) continue;                                  // (j = n - 1 only moves the totals after the chunk: index n)
             atomicAdd(&dl[3][j + 1u], 1);                                      // Vaccinated from j + 1 to the end
-            if (te == TE_SUSCEPTIBLE) { atomicSub(&dl[0][j + 1u], 1); continue; }
+            // (exposed in a LATER step of this chunk: it was Susceptible when it was vaccinated -- only a citizen the repair of the plan
+            // chose anew can look like this, and the chunk is then cut behind step j: that exposure never happened)
+            if (te == TE_SUSCEPTIBLE || (te < TE_RECOVERED && te - TE_BIAS - t0 < n && te - TE_BIAS - t0 > j)) { atomicSub(&dl[0][j + 1u], 1); continue; }
             const int e_last = (int)te - (int)TE_BIAS + (int)d.exposed_time - (int)t0, i_last = e_last + 1 + (int)d.infected_time;
             const int lo = (int)j + 1;
             if (lo <= e_last) { atomicSub(&dl[1][lo], 1); atomicAdd(&dl[1][min(e_last, (int)n - 1) + 1], 1); }
@@ -2391,7 +2469,9 @@ __device__ __forceinline__ uint32_t batch_finish_body(const Dev &d, uint32_t t0,
         ctrl->t = t0 + n_eff; ctrl->steps_done = t0 + n_eff - 1u;
         if (n_eff < n_cut) ctrl->finished = 1u;
         else if (n_cut < n) ctrl->vax_cuts += 1u;
-        ctrl->prev_cut = (n_eff == n_cut && n_cut < n) ? 1u : 0u;
+        // (a chunk whose plan was repaired and that is cut all the same is cut BEHIND a step whose newly chosen citizen mattered later:
+        // what the attempt saw in the step of the cut is then not what will happen in it, so nobody is marked CW_PLAN_SKIP)
+        ctrl->prev_cut = (n_eff == n_cut && n_cut < n && !(vax && ctrl->repair_ran)) ? 1u : 0u;
         if (n_eff) {
             ctrl->lockdown = d.dec[n_eff].lockdown; ctrl->mask = d.dec[n_eff].mask;
             ctrl->at_work = d.dec[n_eff - 1u].at_work; ctrl->bus_dir = d.dec[n_eff - 1u].bus_dir;

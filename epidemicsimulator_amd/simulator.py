@@ -349,7 +349,9 @@ class Simulator:
         """Steps run as chunks under a vaccination programme and how many of those chunks were cut short."""
         ns, nc = C.c_uint64(0), C.c_uint64(0)
         _lib.check(self.lib.esim_vax_chunk_stats(self._ctx, C.byref(ns), C.byref(nc)), self._ctx)
-        return {"steps": ns.value, "cuts": nc.value}
+        nr = C.c_uint64(0)
+        _lib.check(self.lib.esim_vax_repair_stats(self._ctx, C.byref(nr)), self._ctx)
+        return {"steps": ns.value, "cuts": nc.value, "repairs": nr.value}
 
     def pipeline_timing(self):
         ms, nt, nr = C.c_double(0), C.c_uint64(0), C.c_uint64(0)

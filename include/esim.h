@@ -221,13 +221,18 @@ int  esim_chunk_timing(esim_ctx *ctx, double *total_ms, uint64_t *steps, uint64_
  * with few Infected in one launch (census ahead, decisions, marks, draws, books): the Python binding shares it out over the
  * three labels by the kernel's own stage timers (entries and keys 10 %, draws 40 %, census, decisions and books 50 %). */
 enum { ESIM_CK_MARKS = 0, ESIM_CK_FOLD, ESIM_CK_DRAW, ESIM_CK_UNITS, ESIM_CK_COUNT, ESIM_CK_BOOKS, ESIM_CK_SCATTER, ESIM_CK_VAX, ESIM_CK_VAX_ADJ,
-       ESIM_CK_VAX_FINAL, ESIM_CK_DECIDE, ESIM_CK_FUTURE, ESIM_CK_MAP_CLEAR, ESIM_CK_TINY, ESIM_CK_N };
+       ESIM_CK_VAX_FINAL, ESIM_CK_DECIDE, ESIM_CK_FUTURE, ESIM_CK_MAP_CLEAR, ESIM_CK_TINY, ESIM_CK_VAX_REPAIR, ESIM_CK_N };
 int  esim_enable_chunk_kernel_timing(esim_ctx *ctx, int enable);
 int  esim_chunk_kernel_timings(esim_ctx *ctx, double ms[ESIM_CK_N], uint64_t calls[ESIM_CK_N]);
 /* Steps run as time-parallel chunks under a vaccination programme (pipeline level 3: the chunk's vaccinations are planned
  * ahead, simulator.rs:524-553 being a pure function of the step and of citizens_eligible_for_vaccine), and how many of those
  * chunks were cut short because a citizen the plan had chosen left the eligible set on a bus first (simulator.rs:447-449). */
 int  esim_vax_chunk_stats(esim_ctx *ctx, uint64_t *steps, uint64_t *cuts);
+/* Planned chunks in which a citizen was exposed on a bus before the step the plan vaccinates it in, and whose plan was REPAIRED
+ * for the steps behind that exposure (k_chunk_vax<true>: walked again with the eligible set as it truly stood) instead of the
+ * chunk being cut there; a chunk is still cut -- behind the step concerned -- when a newly chosen citizen is Infected or
+ * exposed later in the chunk.  Unsharded contexts; ESIM_VAX_REPAIR=0 switches it off. */
+int  esim_vax_repair_stats(esim_ctx *ctx, uint64_t *repairs);
 /* Record log read-back for split-phase runs (records first..first+n-1, 1-based time steps). */
 int  esim_read_records(esim_ctx *ctx, uint32_t first_step, uint32_t n, esim_step_result *out);
 /* The HIP stream all work of this context is enqueued on (hipStream_t as void*).  esim_set_stream

@@ -36,7 +36,10 @@ SMALL_LIMITS = ("pmap", "vax", "wide", "tinymax", "tp", "pipe", None, 0, 1 << 30
 
 def run_both(pop, steps, check_state_every=None, small_limits=SMALL_LIMITS, **params):
     for lim in small_limits:
-        _run_both(pop, steps, check_state_every, lim, **params)
+        try:
+            _run_both(pop, steps, check_state_every, lim, **params)
+        except AssertionError as e:
+            raise AssertionError("execution form %r: %s" % (lim, e)) from e
 
 
 def _run_both(pop, steps, check_state_every, small_limit, **params):
