@@ -57,6 +57,8 @@ struct esim_ctx_impl {
     bool pmap = false, map_valid = false, pmap_used = false;      // (off by default: measured slower than the per-chunk rebuild)
     uint32_t pmap_since_rebuild = 0, pmap_rebuild_every = 4;
     uint64_t vax_chunk_repairs = 0;
+    bool repair_armed = false;                  // ... its two kernels are enqueued from the first cut of a run on (York never has one: 11 us a chunk saved)
+    bool vax_repair_always = false;             // ESIM_VAX_REPAIR=2: from the start
     bool vax_repair = true;                     // planned chunks: repair the plan after bus exposures instead of cutting the chunk (ESIM_VAX_REPAIR=0: cut)
     uint32_t tiny_pairs = 2048;                 // chunks with at most this many (Infected, step) pairs at the last read-back run as ONE kernel (k_chunk_tiny; 0: off)
     uint32_t small_grid = 64, small_mult = 4;  // chunks with few Infected: workgroups of the marks / fold kernels, multiplier of the draw kernels (0: off)
@@ -436,10 +438,10 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         units = std::min<size_t>(units, (size_t)N / 8u + 65536u);
         d.unit_qcap = (uint32_t)std::max<size_t>(1024, units * 2u / SUBQ);
         if ((rc = dev_alloc(c, &d.units, (size_t)d.unit_qcap * SUBQ))) return rc;
-        if ((rc = dev_alloc(c, &d.route_pairs, (size_t)d.items_cap * 2u))) return rc;
+        if ((rc = dev_alloc(c, &d.route_pairs, (size_t)d.items_cap * (CHUNK_BUS_STEPS / 4u)))) return rc;   // (PAIR_K: up to CHUNK_BUS_STEPS / 4 per item id)
         if ((rc = dev_alloc(c, &d.route_pairs_big, (size_t)d.items_cap * 2u))) return rc;
         HIP_TRY(c, hipMemset(d.units, 0xFF, sizeof(UnitRec) * (size_t)d.unit_qcap * SUBQ));     // code == UNIT_NOOP
-        HIP_TRY(c, hipMemset(d.route_pairs, 0, sizeof(uint32_t) * (size_t)d.items_cap * 2u));
+        HIP_TRY(c, hipMemset(d.route_pairs, 0, sizeof(uint32_t) * (size_t)d.items_cap * (CHUNK_BUS_STEPS / 4u)));
         HIP_TRY(c, hipMemset(d.route_pairs_big, 0, sizeof(uint32_t) * (size_t)d.items_cap * 2u));
         {
             // (a school building's records are those of everybody who works or learns there: its members are in the room lists)
@@ -596,7 +598,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
     if (const char *e = std::getenv("ESIM_GRID_INFECTED")) c->grid_infected = (uint32_t)std::max(1, std::atoi(e));   // tuning knobs
     if (const char *e = std::getenv("ESIM_GRID_CHUNK")) c->grid_chunk = (uint32_t)std::min((int)(CHUNK_WAVES_MAX * 64u / TPB), std::max(16, std::atoi(e) / 16 * 16));   // whole groups of 64 wavefronts
     if (std::getenv("ESIM_TRACE_HOST")) c->host_trace = true;
-    if (const char *e = std::getenv("ESIM_VAX_REPAIR")) c->vax_repair = std::atoi(e) != 0;
+    if (const char *e = std::getenv("ESIM_VAX_REPAIR")) { c->vax_repair = std::atoi(e) != 0; c->vax_repair_always = std::atoi(e) >= 2; }
     if (const char *e = std::getenv("ESIM_TINY_PAIRS")) c->tiny_pairs = (uint32_t)std::max(0, std::atoi(e));
     if (const char *e = std::getenv("ESIM_SMALL_GRID")) c->small_grid = (uint32_t)std::max(0, std::atoi(e) / 16 * 16);
     if (const char *e = std::getenv("ESIM_SMALL_MULT")) c->small_mult = (uint32_t)std::min(16, std::max(1, std::atoi(e)));
@@ -648,7 +650,7 @@ extern "C" int esim_reset(esim_ctx *ctx)
     c->small_ms = 0; c->small_steps = 0;
     c->pkev_used = 0; c->pipe_steps = 0;
     c->chunk_ms = 0; c->chunk_steps = 0; c->chunk_count = 0;
-    c->vax_chunk_steps = 0; c->vax_chunk_cuts = 0; c->elig_seen = false;
+    c->vax_chunk_steps = 0; c->vax_chunk_cuts = 0; c->elig_seen = false; c->repair_armed = false;
     return ESIM_OK;
 }
 
@@ -946,7 +948,7 @@ void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
     kd_mark(c, ESIM_CK_DECIDE);
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 0);
     enqueue_chunk_front(c);
-    if (!pm && d.world == 1u && c->vax_repair) {
+    if (!pm && d.world == 1u && c->vax_repair && (c->repair_armed || c->vax_repair_always)) {
         // bus exposures of citizens the plan vaccinates later: the plan of the steps behind is repaired instead of the chunk being cut
         kd_mark(c, ESIM_CK_VAX_REPAIR);
         hipLaunchKernelGGL(k_chunk_lost, dim3(1), dim3(FIN_TPB), 0, c->stream, d);
@@ -1060,6 +1062,7 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             const uint32_t done = h.t - first;
             c->last_chunk_pairs = h.chunk_pairs;
             if (tk && done) { float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->cev[0], c->cev[1])); c->chunk_ms += ms; c->chunk_steps += done; c->chunk_count += (done + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n; }
+            if (h.vax_cuts > c->vax_chunk_cuts) c->repair_armed = true;   // (a chunk was cut: from now on the plan is repaired instead)
             c->vax_chunk_steps += done; c->vax_chunk_cuts = h.vax_cuts; c->vax_chunk_repairs = h.vax_repairs;
             c->host_t = h.t; total += done; remaining -= done;
             if (h.finished && allow_early_stop) break;

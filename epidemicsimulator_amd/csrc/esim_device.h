@@ -120,6 +120,7 @@ struct Ctrl {
     uint32_t err_where;         // diagnostics: which check raised `error` (ERR_AT_*), reported in esim_last_error
     uint32_t peer_error;        // sharded runs: the error fields of ALL shards, summed (ERR_FIELD): every rank takes its return code
                                 // from this word, so that all leave esim_run_sharded together (k_status_unpack)
+    uint32_t chunk_bus;         // steps of the chunk in preparation with riders on a bus (k_decide)
     uint32_t replan_from;       // first step of the chunk whose plan is walked again (k_chunk_lost; FREE_MAX + 1: none)
     uint32_t repair_ran;        // the plan of the chunk in flight was repaired: a cut it ends in is not one of round 2's kind (no CW_PLAN_SKIP marks)
     uint32_t vax_repairs;       // diagnostics: planned chunks whose plan was repaired after bus exposures instead of being cut (k_chunk_vax<true>)
@@ -324,7 +325,10 @@ enum { ERR_AT_OVF_FULL = 1, ERR_AT_BIG_LIST, ERR_AT_NEG_LIST, ERR_AT_ITEM_IDS, E
 #define NEG_CAP (1u << 18)          // cancellation records per chunk (a chunk plans at most 96 x 8192 vaccinations, few of them of Infected citizens)
 #define UNIT_NOOP 0xFFFFFFFFu
 #define LOST_CAP 8192u              // entries of Dev::lost_list (more: the chunk is cut as before round 3's repair)
-#define CHUNK_BUS_STEPS 8u         // a one-pass chunk has at most this many steps with riders on a bus
+#define CHUNK_BUS_STEPS 32u        // a one-pass chunk has at most this many steps with riders on a bus (a route item keeps a bit per such step;
+                                   // round 3: 8 -- a lockdown that froze the riders on a bus made every chunk 8 steps long)
+// entries a wavefront of k_chunk_marks has for its (route, bus step) pairs: two per item id it owns, more when the chunk has more than 8 bus steps
+#define PAIR_K(per_wave, nbus) ((per_wave) * ((nbus) > 8u ? ((nbus) + 3u) / 4u : 2u))
 #define COUNT_GRID 256u            // workgroups of k_chunk_count
 #define EXP_ROWS 32u
 #define UNIT_PAIRS 256u            // (member, marked step) pairs per deferred unit of a long member list

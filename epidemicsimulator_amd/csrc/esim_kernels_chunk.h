@@ -228,6 +228,7 @@ __device__ __forceinline__ void decide_body(const Dev &d, uint32_t max_ahead, ui
         // there, Q8): that bounds the (route, bus step) pairs a wavefront of k_chunk_marks can register.  The same on all shards.
         const uint32_t bus_steps = (uint32_t)(__popcll(bus_m0) + __popcll(bus_m1));
         ctrl->chunk_parallel = (allow_parallel && ld(&d.xf[d.xf_n]) == 0u && bus_steps <= CHUNK_BUS_STEPS) ? 1u : 0u;
+        ctrl->chunk_bus = bus_steps;
         ctrl->n_items = 0u; ctrl->n_newexp = 0u; ctrl->n_units = 0u; ctrl->unit_next = 0u; ctrl->n_route_pairs = 0u; ctrl->n_route_pairs_big = 0u;
     }
     d.cursor[lane] = 0u;
@@ -1264,7 +1265,8 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
             const bool big = w & FL_BIG_ROUTE;
             const uint32_t rt = src[3];                                       // the route itself, not its item: saves the pass a hop
             // routes of few riders: this wavefront's own stretch of the list, no shared counter; the others share one
-            uint32_t *list = d.route_pairs + (size_t)wave * 2u * per_wave;
+            const uint32_t K = PAIR_K(per_wave, ctrl->chunk_bus);
+            uint32_t *list = d.route_pairs + (size_t)wave * K;
             uint32_t n_big = 0u;
             for (uint32_t i = 0; i < CHUNK_BUS_STEPS; ++i) n_big += (uint32_t)__popcll(__ballot(big && ((new_bits >> i) & 1u)));
             uint32_t big_base = 0u;
@@ -1279,7 +1281,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
                 const unsigned long long ms = __ballot(f && !big), mb = __ballot(f && big);
                 if (f && !big) {
                     const uint32_t pos = my_pairs + (uint32_t)__popcll(ms & lt);
-                    if (pos < 2u * per_wave) list[pos] = (rt << 7) | j; else ctrl->error = (uint32_t)(-ESIM_ERANGE);
+                    if (pos < K) list[pos] = (rt << 7) | j; else ctrl->error = (uint32_t)(-ESIM_ERANGE);
                 }
                 if (f && big && big_base != 0xFFFFFFFFu) d.route_pairs_big[big_base + (uint32_t)__popcll(mb & lt)] = (rt << 7) | j;
                 my_pairs += (uint32_t)__popcll(ms);
@@ -1288,7 +1290,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_marks(Dev d)
             };
             for (unsigned long long m = BUS.lo; m; m &= m - 1ull) put((uint32_t)__builtin_ctzll(m));
             for (uint32_t m = BUS.hi; m; m &= m - 1u) put(64u + (uint32_t)__builtin_ctz(m));
-            my_pairs = min(my_pairs, 2u * per_wave);
+            my_pairs = min(my_pairs, K);
         }
         { const uint32_t pf = PROF_NOW(); ps[0] += pb - pa; ps[1] += pc - pb; ps[2] += pd - pc; ps[3] += pe - pd; ps[4] += pf - pe; }
     }
@@ -1971,7 +1973,7 @@ __global__ __launch_bounds__(TPB) void k_chunk_draw(Dev d, uint32_t n_mw)
     // Wavefront w of k_chunk_marks left pair_cnt[w] pairs in its own stretch of K places.  Its k-th pair goes to the wavefront
     // of this kernel with number ((w + k * PAIR_SPREAD) mod n_mw) + n_mw * (k mod G): lane l of wavefront (base, r) looks at
     // k = l * G + r of the stretch it may have been dealt from.
-    const uint32_t K = 2u * per_wave;                                          // pairs a stretch of the list can hold
+    const uint32_t K = PAIR_K(per_wave, ld(&ctrl->chunk_bus));                 // pairs a stretch of the list can hold
     const uint32_t w_base = wave % n_mw, w_rep = wave / n_mw;
     uint32_t code_l = 0u, off_l = 0u, sz_l = 0u;
     bool have = false;

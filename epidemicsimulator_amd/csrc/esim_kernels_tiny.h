@@ -74,7 +74,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_tiny(Dev d, int do_first, int
     const uint32_t E = i1 - i0;
     bool run = ld(&ctrl->chunk_parallel) != 0u && n != 0u;
     const unsigned long long key_space = (unsigned long long)d.n_bld + d.n_room + d.n_routes;
-    if (run && (i1 < i0 || E > TINY_E || ld(&ctrl->vax_chunk) != 0u || ld(&ctrl->have_elig) != 0u || d.world > 1u || key_space >= 0xFFFFFFFFull || n > FREE_MAX)) {
+    if (run && (i1 < i0 || E > TINY_E || ld(&ctrl->vax_chunk) != 0u || ld(&ctrl->have_elig) != 0u || d.world > 1u || ld(&ctrl->chunk_bus) > 8u || key_space >= 0xFFFFFFFFull || n > FREE_MAX)) {
         // not a chunk for this form: nobody advances (books_body: "the chunk does not run"), the host enqueues the wide form
         __syncthreads();
         if (tid == 0) ctrl->chunk_parallel = 0u;

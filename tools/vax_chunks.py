@@ -17,3 +17,8 @@ while sim._steps < 5000:
     print("steps %4d..%4d: chunk passes %2d (%.2f ms), under the programme %3d steps, cuts so far %3d, repairs %3d, Infected %6d, bus exposures %4d, vaccinated now %5d, eligible %d"
           % (sim._steps - n + 1, sim._steps, kc["chunks"], kc["chunk_ms"], kv["steps"], kv["cuts"], kv["repairs"], int(rec["infected"][-1]), int(rec["exposures_bus"].sum()),
              int(rec["vaccinated_now"][-1]), int(rec["eligible_count"][-1])))
+if "--tail" in sys.argv:
+    sim.reset(); rec = sim.run(5000)
+    for a in range(4700, 5000, 20):
+        r = rec[a:a + 20]
+        print("steps %d..%d lockdown %s riders %s bus exposures %s" % (a + 1, a + 20, "".join(str(int(x)) for x in r["lockdown"]), "".join("1" if x else "0" for x in r["n_riders"]), [int(x) for x in r["exposures_bus"]]))
