@@ -57,6 +57,7 @@ struct esim_ctx_impl {
     bool pmap = false, map_valid = false, pmap_used = false;      // (off by default: measured slower than the per-chunk rebuild)
     uint32_t pmap_since_rebuild = 0, pmap_rebuild_every = 4;
     uint64_t vax_chunk_repairs = 0;
+    bool quiet = false;                         // Ctrl::quiet at the last read-back of a burst of chunk passes
     bool repair_armed = false;                  // ... its two kernels are enqueued from the first cut of a run on (York never has one: 11 us a chunk saved)
     bool vax_repair_always = false;             // ESIM_VAX_REPAIR=2: from the start
     bool vax_repair = true;                     // planned chunks: repair the plan after bus exposures instead of cutting the chunk (ESIM_VAX_REPAIR=0: cut)
@@ -650,7 +651,7 @@ extern "C" int esim_reset(esim_ctx *ctx)
     c->small_ms = 0; c->small_steps = 0;
     c->pkev_used = 0; c->pipe_steps = 0;
     c->chunk_ms = 0; c->chunk_steps = 0; c->chunk_count = 0;
-    c->vax_chunk_steps = 0; c->vax_chunk_cuts = 0; c->elig_seen = false; c->repair_armed = false;
+    c->vax_chunk_steps = 0; c->vax_chunk_cuts = 0; c->elig_seen = false; c->repair_armed = false; c->quiet = false;
     return ESIM_OK;
 }
 
@@ -814,6 +815,7 @@ int run_sequential(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, ui
 {
     Dev &d = c->d;
     c->ctrl_fresh = false;                   // (whatever a burst read back is out of date once more steps are enqueued)
+    c->quiet = false;
     c->map_valid = false;                    // (sequential steps do not maintain the persistent item map)
     uint32_t remaining = n_steps, total = 0;
     int rc;
@@ -932,6 +934,24 @@ void enqueue_parallel_chunk(esim_ctx_impl *c, int then_next, uint32_t limit_t)
 void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
 {
     Dev &d = c->d;
+    if (c->quiet && !(c->pmap && d.world == 1u) && d.world == 1u) {
+        // Nobody is Exposed or Infected any more (the last read-back said so, and nobody is infected from outside): what is left of the
+        // run is the vaccination programme.  No marks, no draws, nothing to scatter: the plan, the decisions, the census the
+        // vaccinations move, the books, the words (York: the last 3400 of its 5000 steps are of this kind).
+        kd_mark(c, ESIM_CK_VAX);
+        hipLaunchKernelGGL(k_chunk_vax<false>, dim3(FREE_MAX + 1u), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 0);
+        kd_mark(c, ESIM_CK_DECIDE);
+        hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 0);
+        c->map_valid = false;
+        kd_mark(c, ESIM_CK_COUNT);
+        hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
+        kd_mark(c, ESIM_CK_BOOKS);
+        hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, 0, 0, (uint32_t)c->xf_n, limit_t);
+        kd_mark(c, ESIM_CK_VAX_FINAL);
+        hipLaunchKernelGGL(k_chunk_vax_final, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d);
+        kd_mark(c, ESIM_CK_N);
+        return;
+    }
     kd_mark(c, ESIM_CK_VAX);
     hipLaunchKernelGGL(k_chunk_vax<false>, dim3(FREE_MAX + 1u), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 0);   // (+ the census ahead)
     // (persistent map: a rebuild has to be decided BEFORE the plan's cancellation records go into the map)
@@ -1062,6 +1082,7 @@ int run_steps(esim_ctx_impl *c, uint32_t n_steps, bool allow_early_stop, uint32_
             const uint32_t done = h.t - first;
             c->last_chunk_pairs = h.chunk_pairs;
             if (tk && done) { float ms; HIP_TRY(c, hipEventElapsedTime(&ms, c->cev[0], c->cev[1])); c->chunk_ms += ms; c->chunk_steps += done; c->chunk_count += (done + (uint32_t)c->xf_n - 1u) / (uint32_t)c->xf_n; }
+            c->quiet = h.quiet != 0u;
             if (h.vax_cuts > c->vax_chunk_cuts) c->repair_armed = true;   // (a chunk was cut: from now on the plan is repaired instead)
             c->vax_chunk_steps += done; c->vax_chunk_cuts = h.vax_cuts; c->vax_chunk_repairs = h.vax_repairs;
             c->host_t = h.t; total += done; remaining -= done;

@@ -120,6 +120,8 @@ struct Ctrl {
     uint32_t err_where;         // diagnostics: which check raised `error` (ERR_AT_*), reported in esim_last_error
     uint32_t peer_error;        // sharded runs: the error fields of ALL shards, summed (ERR_FIELD): every rank takes its return code
                                 // from this word, so that all leave esim_run_sharded together (k_status_unpack)
+    uint32_t quiet;             // nobody was Exposed or Infected in the last step the chunk pass committed: the epidemic is over for good (nobody
+                                // is infected from outside), whatever is left to simulate is the vaccination programme (k_chunk_books)
     uint32_t chunk_bus;         // steps of the chunk in preparation with riders on a bus (k_decide)
     uint32_t replan_from;       // first step of the chunk whose plan is walked again (k_chunk_lost; FREE_MAX + 1: none)
     uint32_t repair_ran;        // the plan of the chunk in flight was repaired: a cut it ends in is not one of round 2's kind (no CW_PLAN_SKIP marks)

@@ -2462,6 +2462,7 @@ __device__ __forceinline__ uint32_t batch_finish_body(const Dev &d, uint32_t t0,
         d.hist[s + TE_BIAS] = exps;
         d.log_off[s + TE_BIAS + 1u] = run0 + (P[ts + 1] - P[top0]);
         if (s <= d.max_steps) d.records[s] = r;
+        if (tid + 1u == n_eff) ctrl->quiet = (r.exposed == 0u && r.infected == 0u) ? 1u : 0u;
     }
     if (tid == 0) {
         ctrl->n_susceptible = S0 - (P[top0 + (int)n_eff] - P[top0]) + cum[0][n_eff];
