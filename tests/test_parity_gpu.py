@@ -448,6 +448,36 @@ def test_chunk_pass_with_few_wavefronts(grid, monkeypatch):
     run_both(pop, 600, check_state_every=97, small_limits=("pmap", "vax", "tp"), **params)
 
 
+@pytest.mark.parametrize("repair", (2, 1, 0))
+def test_bus_exposures_of_planned_citizens_repair_the_plan(repair, monkeypatch):
+    # tools/fuzz_parity.py seed 2026: 700 citizens, 3 vaccinations a step, many bus exposures under the programme.  A citizen the
+    # plan vaccinates later is exposed on a bus first: the plan of the steps behind is walked again (ESIM_VAX_REPAIR=2: from the
+    # start; 1, the default: from the run's first cut on; 0: every such exposure cuts the chunk, as in round 2) -- same records
+    # and states as the oracle in all three, and the repairs and cuts are where they should be.  (The first version of the repair
+    # counted a newly chosen citizen that was exposed LATER in the chunk as Exposed when it was vaccinated: one Susceptible too many.)
+    monkeypatch.setenv("ESIM_VAX_REPAIR", str(repair))
+    rng = np.random.default_rng(7000 + 2026)
+    pop = random_population(2026, n=int(rng.choice([300, 700, 2500])), n_areas=int(rng.choice([1, 5, 12])),
+                            n_buildings=int(rng.choice([40, 90, 400])), n_schools=int(rng.choice([1, 3])), rooms_per_school=int(rng.choice([1, 4, 9])))
+    params = dict(exposure_chance=0.01, seed=207753198333, vaccination_rate=3, vaccination_threshold=0.02, lockdown_threshold=0.9,
+                  mask_pt_threshold=0.02, mask_everywhere_threshold=0.2, bus_capacity=64, exposed_time=96, infected_time=336, start_hour=6, end_hour=17)
+    ep = _lib.default_params(**params)
+    sim = Simulator(pop, ep)
+    orc = _oracle.Oracle(pop, _oracle.params_from_esim(ep))
+    for _ in range(4):
+        assert_same_records(sim.run(125), orc.run(125))
+        assert_same_state(sim, orc)
+    st = sim.vax_chunk_stats()
+    assert st["steps"] > 100
+    if repair == 2:
+        assert st["repairs"] >= 2
+    elif repair == 0:
+        assert st["repairs"] == 0 and st["cuts"] >= 2
+    else:
+        assert st["cuts"] >= 1
+    sim.close()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_populations_all_paths(seed):
     pop = random_population(seed)
