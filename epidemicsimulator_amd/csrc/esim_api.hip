@@ -561,6 +561,8 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         if ((rc = dev_upload(c, &d.shared_of_room, of_r.data(), of_r.size()))) return rc;
         if ((rc = dev_alloc(c, &d.xv, XV_HEADER + (size_t)FREE_MAX * (PLAN_W / 32u)))) return rc;
         if ((rc = dev_alloc(c, &d.xc, FREE_MAX + 2u))) return rc;
+        if ((rc = dev_alloc(c, &d.xl, FREE_MAX + 2u))) return rc;
+        HIP_TRY(c, hipMemset(d.xl, 0, sizeof(uint32_t) * (FREE_MAX + 2u)));
         if ((rc = dev_alloc(c, &d.xe, XE_WORDS))) return rc;
         HIP_TRY(c, hipMemset(d.xe, 0, sizeof(uint32_t) * XE_WORDS));
         HIP_TRY(c, hipMemset(d.xv, 0, sizeof(uint32_t) * (XV_HEADER + (size_t)FREE_MAX * (PLAN_W / 32u))));
@@ -1572,7 +1574,7 @@ int enqueue_sharded_chunk(esim_ctx_impl *c, uint32_t limit_t, bool vax)
     int rc;
     hipLaunchKernelGGL(k_future, dim3(1), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
     if (vax) {
-        hipLaunchKernelGGL(k_vax_live, dim3(PLAN_W / TPB, FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+        hipLaunchKernelGGL(k_vax_live<false>, dim3(PLAN_W / TPB, FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
         if ((rc = exchange_buf(c, 3, d.xv, XV_HEADER + (size_t)FREE_MAX * (PLAN_W / 32u)))) return rc;
         hipLaunchKernelGGL(k_chunk_vax<false>, dim3(FREE_MAX), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1);
         hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 0);
@@ -1598,6 +1600,16 @@ int enqueue_sharded_chunk(esim_ctx_impl *c, uint32_t limit_t, bool vax)
     hipLaunchKernelGGL(k_chunk_fold<false>, dim3(c->grid_chunk), dim3(TPB), 0, c->stream, d);
     hipLaunchKernelGGL(k_chunk_draw<false>, dim3(c->grid_chunk * c->draw_mult), dim3(TPB), 0, c->stream, d, c->grid_chunk * (TPB / 64u));
     hipLaunchKernelGGL(k_chunk_units<false>, dim3(c->grid_chunk * c->units_mult), dim3(TPB), 0, c->stream, d);
+    if (vax && c->vax_repair && (c->repair_armed || c->vax_repair_always)) {
+        // the repair of the plan (DESIGN.md 3.13 v), sharded: the shards agree on the step to walk again from (buffer L), exchange
+        // the liveness of the candidates as it truly stood (buffer V a second time) and walk the same steps again
+        hipLaunchKernelGGL(k_chunk_lost, dim3(1), dim3(FIN_TPB), 0, c->stream, d);
+        if ((rc = exchange_buf(c, 10, d.xl, FREE_MAX + 2u))) return rc;
+        hipLaunchKernelGGL(k_lost_global, dim3(1), dim3(64), 0, c->stream, d);
+        hipLaunchKernelGGL(k_vax_live<true>, dim3(PLAN_W / TPB, FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
+        if ((rc = exchange_buf(c, 3, d.xv, XV_HEADER + (size_t)FREE_MAX * (PLAN_W / 32u)))) return rc;
+        hipLaunchKernelGGL(k_chunk_vax<true>, dim3(FREE_MAX), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1);
+    }
     hipLaunchKernelGGL(k_chunk_count, dim3(COUNT_GRID), dim3(TPB), 0, c->stream, d);
     if (vax && (rc = exchange_buf(c, 5, d.xc, FREE_MAX + 2u))) return rc;
     hipLaunchKernelGGL(k_chunk_books, dim3(1), dim3(FIN_TPB), 0, c->stream, d, 0, 0, (uint32_t)c->xf_n, limit_t);
@@ -1669,6 +1681,8 @@ extern "C" int esim_run_sharded(esim_ctx *ctx, uint32_t n_steps, uint32_t *n_don
             const uint32_t done = h.t - t_first;
             c->host_t = h.t; remaining -= done;
             c->shard_chunk_steps += done;
+            if (h.vax_cuts > c->vax_chunk_cuts) c->repair_armed = true;  // (cuts are decided from summed words: every rank arms in the same burst)
+            c->vax_chunk_cuts = h.vax_cuts; c->vax_chunk_repairs = h.vax_repairs;
             // the commuter segment follows the need (the same on every rank: the counts were gathered)
             const uint32_t cap_before = d.xs_cap;
             while (d.xs_cap < XS_CAP_MAX && 2u * h.xs_need_all > d.xs_cap) d.xs_cap *= 2u;     // (xs_need_all: the maximum over the shards, from the status exchange)

@@ -280,6 +280,8 @@ struct Dev {
     uint32_t *xs_out;                   // [world][1 + 3 * xs_cap] what this shard sends to each of the others (nullptr: the all-gather form)
     const uint32_t *shared_mask;        // [n_shared_bld] bit r: shard r has members in the shared building (summed at set-up)
     uint32_t *xc;                       // [FREE_MAX + 2] steps of the chunk with a cut (k_chunk_count)
+    uint32_t *xl;                       // [FREE_MAX + 2] steps of the chunk in which a citizen of THIS shard left the eligible set on a bus with a planned
+                                        // vaccination in its word (k_chunk_lost; summed: the shards walk the plan again from the same step)
     uint32_t *xe;                       // [XE_WORDS] status exchange: [0] error fields (ERR_FIELD), [1] shards that are finished, [2 + r] the most
                                         // commuter records shard r wanted to send to one destination in the chunk last prepared
     const int32_t *shared_of_bld, *shared_of_room;   // [n_bld], [n_room]: index into the shared tables, -1 when not shared

@@ -258,21 +258,32 @@ __global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32
 // Sharded runs: a candidate's eligibility is known to the shard that owns the citizen.  k_vax_live writes, for every step of
 // the chunk ahead, the liveness bits of its first PLAN_W candidates (own citizens only; the shards SUM-all-reduce buffer V, the
 // bits being disjoint) and, in the header, this shard's eligible count, riders and whether it can plan at all.
+// REPAIR (k_vax_live<true>, before k_chunk_vax<true> walks the steps from Ctrl::replan_from on again): the liveness as it truly stood
+// in each of those steps (eligible by the final word, or exposed on a bus in a LATER step of the chunk); the other steps' rows are
+// zeroed (the buffer is summed in place a second time).
+template <bool REPAIR>
 __global__ __launch_bounds__(TPB) void k_vax_live(Dev d, uint32_t max_ahead, uint32_t limit_t)
 {
     Ctrl *ctrl = d.ctrl;
     const uint32_t j = blockIdx.y, i = blockIdx.x * TPB + threadIdx.x;
     const uint32_t t0 = ctrl->t;
-    const uint32_t n_ahead = t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead);
+    const uint32_t n_chunk = ctrl->chunk_ok, from = ctrl->replan_from;
+    const uint32_t n_ahead = REPAIR ? ((ctrl->vax_chunk && ctrl->chunk_parallel && from < n_chunk) ? n_chunk : 0u)
+                                    : (t0 > limit_t ? 0u : (limit_t - t0 + 1u < max_ahead ? limit_t - t0 + 1u : max_ahead));
     if (j == 0 && blockIdx.x == 0 && threadIdx.x < XV_HEADER) {
         const uint32_t k = threadIdx.x;
         d.xv[k] = k == 0 ? ctrl->elig_count : k == 1 ? d.n_pt : k == 2 ? ((ctrl->finished || ctrl->error) ? 1u : 0u) : 0u;
-        if (k == 0) ctrl->vax_fail = 0u;
+        if (k == 0 && !REPAIR) ctrl->vax_fail = 0u;
     }
     bool live = false;
-    if (ctrl->have_elig && j < n_ahead) {
+    if (ctrl->have_elig && j < n_ahead && (!REPAIR || j >= from)) {
         const uint32_t cand = vacc_candidate(d, i, t0 + j);
-        if (cand >= d.id_base && cand - d.id_base < d.n) { const uint32_t w = d.cit[cand - d.id_base]; live = eligible(w, ctrl->trigger_step) && !(w & CW_PLAN_SKIP); }
+        if (cand >= d.id_base && cand - d.id_base < d.n) {
+            const uint32_t w = d.cit[cand - d.id_base];
+            const uint32_t e = CW_TE(w) - TE_BIAS - t0;
+            const bool later_bus = REPAIR && (w & CW_BUS_EXPOSED) && CW_TE(w) < TE_RECOVERED && e < n_chunk && e > j;
+            live = (eligible(w, ctrl->trigger_step) || later_bus) && !(w & CW_PLAN_SKIP);
+        }
     }
     const unsigned long long m = __ballot(live);
     if ((threadIdx.x & 63u) == 0) { uint32_t *row = d.xv + XV_HEADER + (size_t)j * (PLAN_W / 32u); row[i >> 5] = (uint32_t)m; row[(i >> 5) + 1u] = (uint32_t)(m >> 32); }
@@ -293,21 +304,43 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_lost(Dev d)
     const uint32_t tid = threadIdx.x;
     const uint32_t n_chunk = ctrl->chunk_ok, t0 = ctrl->t;
     const uint32_t n_lost = d.hot[HOT_LOST * HOT_STRIDE];
-    if (!ctrl->vax_chunk || !ctrl->chunk_parallel || n_chunk == 0u || n_lost == 0u || n_lost > LOST_CAP) return;   // (more than the list holds: cut as before)
+    if (!ctrl->vax_chunk || !ctrl->chunk_parallel || n_chunk == 0u || n_lost == 0u) return;
     if (tid == 0) s_from = FREE_MAX + 1u;
     __syncthreads();
     uint32_t lo = FREE_MAX + 1u;
-    for (uint32_t i = tid; i < n_lost; i += FIN_TPB) {
-        const uint32_t m = d.lost_list[i];
-        if (m >= d.n) continue;
+    auto look = [&](uint32_t m) {
+        if (m >= d.n) return;
         const uint32_t w = d.cit[m], e = CW_TE(w) - TE_BIAS - t0;
-        if (!(w & CW_BUS_EXPOSED) || CW_TE(w) >= TE_RECOVERED || e >= n_chunk || CW_VAX_REL(w) == CW_VAX_NONE) continue;   // (listed twice: cleared already)
+        if (!(w & CW_BUS_EXPOSED) || CW_TE(w) >= TE_RECOVERED || e >= n_chunk || CW_VAX_REL(w) == CW_VAX_NONE) return;   // (listed twice: cleared already)
         lo = min(lo, e);
         atomicAnd(&d.cit[m], ~CW_VAX_MASK);
+        if (d.world > 1u) d.xl[e] = 1u;
+    };
+    if (n_lost <= LOST_CAP) for (uint32_t i = tid; i < n_lost; i += FIN_TPB) look(d.lost_list[i]);
+    else {
+        // (more than the list holds: everybody exposed in the chunk is looked at)
+        const uint32_t r = tid & (SUBQ - 1u);
+        const uint32_t n_new = min(d.hot[(HOT_NEWEXP + r) * HOT_STRIDE], d.newexp_cap);
+        const uint32_t *list = d.newexp + (size_t)r * d.newexp_cap;
+        for (uint32_t i = tid / SUBQ; i < n_new; i += FIN_TPB / SUBQ) look(list[i]);
     }
     if (lo <= FREE_MAX) atomicMin(&s_from, lo);
     __syncthreads();
+    if (d.world > 1u) return;                                                 // (sharded: the earliest step of ALL shards, k_lost_global)
     if (tid == 0 && s_from <= FREE_MAX) { ctrl->replan_from = s_from; ctrl->repair_ran = 1u; ctrl->vax_repairs += 1u; }
+}
+
+// Sharded: buffer L summed over the shards -- the plan is walked again from the earliest step in which ANY shard lost a citizen.
+__global__ __launch_bounds__(64) void k_lost_global(Dev d)
+{
+    Ctrl *ctrl = d.ctrl;
+    const uint32_t lane = threadIdx.x, n = ctrl->chunk_ok;
+    if (!ctrl->vax_chunk || !ctrl->chunk_parallel || n == 0u) return;
+    const unsigned long long m0 = __ballot(lane < n && d.xl[lane] != 0u), m1 = __ballot(64u + lane < n && d.xl[64u + lane] != 0u);
+    if (lane == 0 && (m0 | m1)) {
+        ctrl->replan_from = m0 ? (uint32_t)__ffsll((long long)m0) - 1u : 64u + (uint32_t)__ffsll((long long)m1) - 1u;
+        ctrl->repair_ran = 1u; ctrl->vax_repairs += 1u;
+    }
 }
 
 // REPAIR (k_chunk_vax<true>, after the draws of the chunk, before its counts; unsharded contexts on the per-chunk map): a citizen the
@@ -430,7 +463,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead
                                 if (e > (int)j && e < (int)n_chunk) bad = true;
                                 if (max(a, (int)j + 1) <= min(b, (int)n_chunk - 1)) bad = true;
                             }
-                            if (bad) atomicMin(&ctrl->chunk_cut, j + 1u);
+                            if (bad) { atomicMin(&ctrl->chunk_cut, j + 1u); if (d.world > 1u) d.xc[j + 1u] = 1u; }
                         }
                     }
                 }
@@ -440,7 +473,11 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead
         const uint32_t got = sm.s_total;
         __syncthreads();
         already += got < k - already ? got : k - already;
-        if (sharded && base + VACC_BATCH >= PLAN_W && already < k) { if (tid == 0) atomicAdd(&ctrl->vax_fail, 1u); break; }   // the window was too short: no plan
+        if (sharded && base + VACC_BATCH >= PLAN_W && already < k) {
+            // the exchanged window was too short: no plan -- or, walking a step again: the chunk ends in front of this step
+            if (tid == 0) { if (REPAIR) { atomicMin(&ctrl->chunk_cut, j); d.xc[j] = 1u; } else atomicAdd(&ctrl->vax_fail, 1u); }
+            break;
+        }
         if (base >= (1u << 26) && already < k) { if (tid == 0) ctrl->error = (uint32_t)(-ESIM_ERANGE); break; }   // every wave must reach an exit
     }
     __syncthreads();
@@ -564,7 +601,7 @@ __global__ __launch_bounds__(128) void k_shard_prep(Dev d, uint32_t max_ahead, u
         uint32_t a = 0u;
         for (uint32_t j = 0; j < n_ahead; ++j) { a += d.xf_adj[j]; d.xf[j] += a; }
     }
-    for (uint32_t j = 0; j < FREE_MAX + 2u; ++j) d.xc[j] = 0u;
+    for (uint32_t j = 0; j < FREE_MAX + 2u; ++j) { d.xc[j] = 0u; d.xl[j] = 0u; }
 }
 
 // Marks of the first step of a chunk (the later ones are made by the k_pipe of the step before).

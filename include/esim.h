@@ -231,7 +231,8 @@ int  esim_vax_chunk_stats(esim_ctx *ctx, uint64_t *steps, uint64_t *cuts);
 /* Planned chunks in which a citizen was exposed on a bus before the step the plan vaccinates it in, and whose plan was REPAIRED
  * for the steps behind that exposure (k_chunk_vax<true>: walked again with the eligible set as it truly stood) instead of the
  * chunk being cut there; a chunk is still cut -- behind the step concerned -- when a newly chosen citizen is Infected or
- * exposed later in the chunk.  Unsharded contexts; ESIM_VAX_REPAIR=0 switches it off. */
+ * exposed later in the chunk.  Sharded runs do the same with two more exchanges per planned chunk (the steps in which a shard lost
+ * a citizen, callback `which` 10; the candidates' liveness a second time, `which` 3).  ESIM_VAX_REPAIR=0 switches it off. */
 int  esim_vax_repair_stats(esim_ctx *ctx, uint64_t *repairs);
 /* Record log read-back for split-phase runs (records first..first+n-1, 1-based time steps). */
 int  esim_read_records(esim_ctx *ctx, uint32_t first_step, uint32_t n, esim_step_result *out);

@@ -74,6 +74,11 @@ def main():
         assert st["chunk_steps"] > 0, st                      # the default form draws chunks wherever it can
     if cfg.get("expect_coupled"):
         assert st["coupled_steps"] >= cfg["expect_coupled"], st
+    if cfg.get("expect_repairs"):
+        import ctypes as C
+        nr = C.c_uint64(0)
+        _lib.check(sim.lib.esim_vax_repair_stats(sim._ctx, C.byref(nr)), sim._ctx)
+        assert nr.value >= cfg["expect_repairs"], ("plans repaired", nr.value)
     dist.barrier()
     sim.close()
     dist.destroy_process_group()

@@ -116,6 +116,19 @@ def test_few_eligible_candidates_need_more_than_one_batch():
     assert all("ok" in o for o in outs)
 
 
+@pytest.mark.parametrize("world", (2, 3))
+def test_sharded_plans_are_repaired_after_bus_exposures(world):
+    # many bus exposures under a programme that vaccinates a tenth of the world per step: citizens the plan vaccinates later are
+    # exposed on a bus first, in every chunk.  ESIM_VAX_REPAIR=2: the shards agree on the step to walk the plan again from (buffer
+    # L), exchange the candidates' liveness as it truly stood and walk the same steps again -- records and states as the oracle's
+    cfg = dict(backend="gloo", cuts="even", spec=dict(n_citizens=9000, n_areas=30, citizens_per_school=2500, n_seeds=40),
+               params=dict(exposure_chance=0.02, vaccination_rate=60, vaccination_threshold=0.01, lockdown_threshold=0.9, mask_pt_threshold=0.9,
+                           mask_everywhere_threshold=0.95, bus_capacity=60, seed=5, max_steps=700), steps=480, chunk=160,
+               expect=dict(vaccinated=1000), expect_repairs=2, env_by_rank={str(r): {"ESIM_VAX_REPAIR": "2"} for r in range(world)})
+    outs = launch(world, cfg)
+    assert all("ok" in o for o in outs)
+
+
 def test_a_rank_whose_chunks_never_fit_takes_every_rank_to_coupled_steps():
     # ESIM_HASH_LOG2=4 on rank 1 only: its chunks can never take the one-pass form, rank 0's can.  The "cannot" word of buffer F
     # is summed, so both ranks skip the chunk together and back off to coupled steps -- same records as the oracle
