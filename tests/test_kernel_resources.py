@@ -35,3 +35,7 @@ def test_no_kernel_uses_scratch_and_the_hot_kernels_keep_their_occupancy(tmp_pat
         if "k_chunk_draw" in name or "k_chunk_units" in name or "k_chunk_marks" in name:
             assert r["Occupancy [waves/SIMD]"] >= 4, (name, r)
             assert r["VGPRs"] <= 128, (name, r)
+        # ... and k_chunk_draw a fifth (its grid is four times the marks grid: the dispatcher keeps five wavefronts per SIMD resident;
+        # a change that took it from 94 to 106 registers cost 10 % of the kernel with every parity test green)
+        if "k_chunk_draw" in name:
+            assert r["Occupancy [waves/SIMD]"] >= 5 and r["VGPRs"] <= 96, (name, r)
