@@ -408,10 +408,10 @@ def random_population(seed, n=700, n_areas=5, n_buildings=90, n_schools=3, rooms
 
 
 def test_one_huge_workplace_overflows_a_unit_queue():
-    # 9000 citizens who all work in ONE building: its worker list is 9000 x 32 work steps = 288 000 (member, step) pairs
-    # per chunk = 1125 units of 256, more than one unit queue holds (1024): the producing wavefront has to draw the
-    # list itself; households of four, a second area so that half of the workers fail the same-area filter
-    n = 9000
+    # 50 000 citizens who all work in ONE building: its worker list is 50 000 members x up to 25 slots of four steps = 1 250 000
+    # (member, slot) pairs per chunk = 1221 units of 1024, more than the queue it goes to holds (1024): the producing wavefront
+    # has to draw the list itself; households of four, a second area so that half of the workers fail the same-area filter
+    n = 50000
     home = (np.arange(n, dtype=np.uint32) // 4)
     n_home = int(home.max()) + 1
     work = np.full(n, n_home, np.uint32)
