@@ -432,7 +432,7 @@ extern "C" int esim_upload_population(esim_ctx *ctx, const esim_population *pop)
         auto add_lists = [&](const std::vector<uint32_t> &off) {
             for (size_t i = 0; i + 1 < off.size(); ++i) {
                 const size_t pairs = (size_t)(off[i + 1] - off[i]) * FREE_MAX;
-                if (pairs > UNIT_PAIRS) units += (pairs + UNIT_PAIRS - 1) / UNIT_PAIRS;
+                if (pairs > UNIT_INLINE) units += (pairs + UNIT_PAIRS - 1) / UNIT_PAIRS;
             }
         };
         add_lists(res_off); add_lists(wrk_off); add_lists(room_off);

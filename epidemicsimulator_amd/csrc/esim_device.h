@@ -335,6 +335,9 @@ enum { ERR_AT_OVF_FULL = 1, ERR_AT_BIG_LIST, ERR_AT_NEG_LIST, ERR_AT_ITEM_IDS, E
 #define PAIR_K(per_wave, nbus) ((per_wave) * ((nbus) > 8u ? ((nbus) + 3u) / 4u : 2u))
 #define COUNT_GRID 256u            // workgroups of k_chunk_count
 #define EXP_ROWS 32u
+#ifndef UNIT_INLINE
+#define UNIT_INLINE 1024u          // the longest list (in pairs) a wavefront of k_chunk_draw draws itself
+#endif
 #ifndef UNIT_PAIRS
 #define UNIT_PAIRS 1024u           // (member, marked step) pairs per deferred unit of a long member list, and the longest list a wavefront of
                                    // k_chunk_draw draws itself (128 ... 16384 measured: DESIGN.md 3.9, 3.13 viii)

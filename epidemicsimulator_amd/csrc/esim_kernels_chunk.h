@@ -1749,7 +1749,7 @@ __device__ __forceinline__ void list_or_units(const Dev &d, Ctrl *ctrl, const Ch
 {
     const uint32_t pairs = (hi - lo) * S;
     if (pairs == 0) return;
-    if (pairs <= UNIT_PAIRS) { member_pairs(d, ctrl, sm, ws, idx, lo, 0u, pairs, lane, kind, S, t0 WORK_PASS, have_pre, pre_m, pre_w); return; }
+    if (pairs <= UNIT_INLINE) { member_pairs(d, ctrl, sm, ws, idx, lo, 0u, pairs, lane, kind, S, t0 WORK_PASS, have_pre, pre_m, pre_w); return; }
     const uint32_t n_units = (pairs + UNIT_PAIRS - 1u) / UNIT_PAIRS;
     const uint32_t r = ((blockIdx.x * TPB + threadIdx.x) >> 6) & (SUBQ - 1u);  // this wavefront's queue
     uint32_t start = 0;
