@@ -328,7 +328,9 @@ enum { ERR_AT_OVF_FULL = 1, ERR_AT_BIG_LIST, ERR_AT_NEG_LIST, ERR_AT_ITEM_IDS, E
 #define PBIG_STRIDE 4u             // words per entry of the persistent map's fold list: slot, overflow base, capacity | school flag, school
 #define NEG_CAP (1u << 18)          // cancellation records per chunk (a chunk plans at most 96 x 8192 vaccinations, few of them of Infected citizens)
 #define UNIT_NOOP 0xFFFFFFFFu
-#define LOST_CAP 8192u              // entries of Dev::lost_list (more: the chunk is cut as before round 3's repair)
+#ifndef LOST_CAP
+#define LOST_CAP 8192u              // entries of Dev::lost_list (more: k_chunk_lost looks at everybody exposed in the chunk instead; -DLOST_CAP=2 tested)
+#endif
 #define CHUNK_BUS_STEPS 32u        // a one-pass chunk has at most this many steps with riders on a bus (a route item keeps a bit per such step;
                                    // round 3: 8 -- a lockdown that froze the riders on a bus made every chunk 8 steps long)
 // entries a wavefront of k_chunk_marks has for its (route, bus step) pairs: two per item id it owns, more when the chunk has more than 8 bus steps
