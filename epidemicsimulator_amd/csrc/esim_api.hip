@@ -965,8 +965,10 @@ void enqueue_vax_chunk(esim_ctx_impl *c, uint32_t limit_t)
         (void)hipMemsetAsync(d.sch_ring, 0, sizeof(uint32_t) * (size_t)(d.n_sch ? d.n_sch : 1) * 2u * SCH_RING, c->stream);
         c->pmap_since_rebuild = 0; c->map_valid = true;
     }
-    kd_mark(c, ESIM_CK_VAX_ADJ);
-    hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, pm ? 1 : 0);
+    if (pm) {                                     // (the plan's vaccinations of citizens the persistent map holds: noted for k_map_enter)
+        kd_mark(c, ESIM_CK_VAX_ADJ);
+        hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1);
+    }
     kd_mark(c, ESIM_CK_DECIDE);
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1, 0);
     enqueue_chunk_front(c);
@@ -1577,7 +1579,6 @@ int enqueue_sharded_chunk(esim_ctx_impl *c, uint32_t limit_t, bool vax)
         hipLaunchKernelGGL(k_vax_live<false>, dim3(PLAN_W / TPB, FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t);
         if ((rc = exchange_buf(c, 3, d.xv, XV_HEADER + (size_t)FREE_MAX * (PLAN_W / 32u)))) return rc;
         hipLaunchKernelGGL(k_chunk_vax<false>, dim3(FREE_MAX), dim3(FIN_TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 1);
-        hipLaunchKernelGGL(k_chunk_vax_adj, dim3(FREE_MAX), dim3(TPB), 0, c->stream, d, (uint32_t)c->xf_n, limit_t, 0);
     }
     const size_t seg = 1u + 3u * (size_t)d.xs_cap;
     if (d.xs_out) {

@@ -233,6 +233,9 @@ __device__ __forceinline__ void decide_body(const Dev &d, uint32_t max_ahead, ui
     }
     d.cursor[lane] = 0u;
     if (lane < FREE_MAX - 64u) d.cursor[64u + lane] = 0u;
+    // (the plan's census adjustments have been used -- by this kernel, or folded into buffer F by k_shard_prep --: zero for the next plan)
+    d.xf_adj[lane] = 0u;
+    if (lane < FREE_MAX + 2u - 64u) d.xf_adj[64u + lane] = 0u;
 }
 
 __global__ __launch_bounds__(64) void k_decide(Dev d, uint32_t max_ahead, uint32_t limit_t, int allow_parallel, int adj_folded)
@@ -383,8 +386,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead
                       elig_all > d.vaccination_rate + riders_all;      // the set cannot shrink to the "whole set" case inside the chunk
     if (REPAIR) { if (tid == 0) { d.vax_cnt[j] = 0u; d.vax_now[j] = 0u; n_local = 0u; } }
     else if (tid == 0) {
-        d.xf_adj[j] = 0u;
-        for (uint32_t q = 0; q < 4u; ++q) d.vax_delta[q * (FREE_MAX + 2u) + j] = 0u;
+        for (uint32_t q = 0; q < 4u; ++q) d.vax_delta[q * (FREE_MAX + 2u) + j] = 0u;                // (xf_adj: zero since the last k_decide)
         d.vax_cnt[j] = 0u; d.vax_now[j] = 0u;
         n_local = 0u;
         if (j == 0) {
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead
             ctrl->n_neg = 0u; ctrl->n_cancel = 0u;
             if (!sharded) ctrl->vax_fail = 0u;
             ctrl->chunk_cut = FREE_MAX + 1u;
-            for (uint32_t z = FREE_MAX; z < FREE_MAX + 2u; ++z) { d.xf_adj[z] = 0u; for (uint32_t q = 0; q < 4u; ++q) d.vax_delta[q * (FREE_MAX + 2u) + z] = 0u; }
+            for (uint32_t z = FREE_MAX; z < FREE_MAX + 2u; ++z) for (uint32_t q = 0; q < 4u; ++q) d.vax_delta[q * (FREE_MAX + 2u) + z] = 0u;
         }
     }
     if (!plan || j >= n_ahead) return;
@@ -452,6 +454,20 @@ __global__ __launch_bounds__(FIN_TPB) void k_chunk_vax(Dev d, uint32_t max_ahead
                     // unconditional (simulator.rs:551) -- but a citizen that is Vaccinated already stays what it is
                     if (CW_TE(cw[q]) != TE_VACCINATED) {
                         const uint32_t old = atomicMax(&d.cit[c], (cw[q] & ~CW_VAX_MASK) | CW_VAX_FIELD(j));
+                        if (!REPAIR && CW_TE(cw[q]) < TE_RECOVERED && (CW_VAX_REL(old) == CW_VAX_NONE || CW_VAX_REL(old) > j)) {
+                            // The Infected census ahead (buffer F) counts everybody whose exposure step makes it Infected; those the plan
+                            // vaccinates before leave it: the stretch of the chunk in which this citizen would have been Infected behind
+                            // step j goes into the difference array xf_adj (k_decide adds its prefix sums to F) -- for the step that WINS:
+                            // a step that takes the citizen over from a later one takes that one's stretch out again (round 3: a
+                            // kernel of its own did this from the final words, k_chunk_vax_adj).
+                            const int a = (int)CW_TE(cw[q]) - (int)TE_BIAS + (int)d.exposed_time + 1 - (int)t0, hi = min(a + (int)d.infected_time, (int)n_ahead - 1);
+                            const int lo = max(a, (int)j + 1);
+                            if (lo <= hi) { atomicSub(&d.xf_adj[lo], 1u); atomicAdd(&d.xf_adj[hi + 1], 1u); }
+                            if (CW_VAX_REL(old) != CW_VAX_NONE) {
+                                const int lo2 = max(a, (int)CW_VAX_REL(old) + 1);
+                                if (lo2 <= hi) { atomicAdd(&d.xf_adj[lo2], 1u); atomicSub(&d.xf_adj[hi + 1], 1u); }
+                            }
+                        }
                         if (REPAIR && (CW_VAX_REL(old) == CW_VAX_NONE || CW_VAX_REL(old) > j)) {
                             // newly chosen for this step (or moved here from a later one): harmless unless something it did behind
                             // step j mattered -- Infected in a later step of the chunk, or exposed in one
@@ -502,8 +518,6 @@ __global__ __launch_bounds__(TPB) void k_chunk_vax_adj(Dev d, uint32_t max_ahead
         const uint32_t w = d.cit[cz], te = CW_TE(w);
         if (CW_VAX_REL(w) != j || te >= TE_RECOVERED) continue;                // not the winning step / never exposed
         const int a = (int)te - (int)TE_BIAS + (int)d.exposed_time + 1 - (int)t0;   // Infected in steps [a, a + infected_time] of the chunk
-        const int lo = a > (int)j + 1 ? a : (int)j + 1, hi = min(a + (int)d.infected_time, (int)n_ahead - 1);
-        if (lo <= hi) { atomicSub(&d.xf_adj[lo], 1u); atomicAdd(&d.xf_adj[hi + 1], 1u); }
         // persistent map: a citizen it holds already (k_map_enter handles those that turn Infected in this chunk) and whose stretch
         // reaches beyond step j is cancelled from step j + 1 on -- to the end of its stretch, whatever the chunk's length
         // (noted here, entered by k_map_enter once the chunk's length is known: a step beyond its end is not committed by it)
