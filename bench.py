@@ -305,7 +305,7 @@ def main():
             hbm = {"achieved_GBs": hbm_bytes / dur_s / 1e9, "peak_GBs": HBM_PEAK_GBS, "frac": hbm_bytes / dur_s / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": hbm_bytes,
                    "read_requests_32B_64B_128B_per_launch": [x / pk["calls"] for x in pk["read_requests_32B_64B_128B"]]}
             valu = {"busy_simd_cycles_per_launch": valu_cyc, "frac_at_2.4GHz": valu_cyc / (N_SIMD * 2.4e9 * dur_s), "frac_at_2.1GHz": valu_cyc / (N_SIMD * 2.1e9 * dur_s),
-                    "resident_wavefronts_per_simd_at_2.4GHz": wave_cyc / (N_SIMD * 2.4e9 * dur_s), "launched_wavefronts_per_simd": 4.0,
+                    "resident_wavefronts_per_simd_at_2.4GHz": wave_cyc / (N_SIMD * 2.4e9 * dur_s), "wavefronts_per_simd_that_fit": 5.0,   # (96 registers: tests/test_kernel_resources.py; the grid is 16 per SIMD over a launch)
                     "note": "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x clock x launch duration); the chip holds 2.1-2.4 GHz under this load"}
             near_valu = valu["frac_at_2.4GHz"] >= hbm["frac"]
             rf = {"bound": "valu" if near_valu else "hbm",
